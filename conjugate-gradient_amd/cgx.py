@@ -1,0 +1,268 @@
+"""ctypes binding of libcgx.so (include/cgx.h) plus a Python mirror of the reference's CGSolver.
+
+Only test/bench plumbing lives here: every number is computed by the HIP library.  There is no CPU
+fallback: if libcgx.so is missing or no MI355X is visible, the calls raise.
+Reference interface mirrored: class CGSolver, code/MPI/cg.hh:11-57 and code/CUDA/cg.hh:13-45.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libcgx.so")
+UNIQUE_ID_BYTES = 128
+
+COMM_SELF, COMM_LOOPBACK, COMM_RCCL = 0, 1, 2
+
+EXPORTS = [
+    "cgx_config_init", "cgx_comm_unique_id", "cgx_create", "cgx_destroy", "cgx_last_error", "cgx_status_string",
+    "cgx_partition", "cgx_generate_lap2d_matrix", "cgx_set_matrix_dense", "cgx_read_matrix",
+    "cgx_init_source_term", "cgx_set_source_term", "cgx_set_max_iter", "cgx_set_tolerance", "cgx_get_size",
+    "cgx_solve", "cgx_solve_begin", "cgx_solve_steps", "cgx_solve_end",
+    "cgx_probe_gemv", "cgx_probe_vector_ops", "cgx_probe_get_matrix_rows",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("struct_version", C.c_int), ("comm_mode", C.c_int), ("device", C.c_int), ("rank", C.c_int),
+        ("nranks", C.c_int), ("unique_id", C.c_ubyte * UNIQUE_ID_BYTES), ("gemv_variant", C.c_int),
+        ("lda_pad", C.c_int), ("check_every", C.c_int), ("profile_gemv", C.c_int), ("use_graph", C.c_int),
+        ("reserved", C.c_int * 8),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("iterations", C.c_int), ("converged", C.c_int), ("residual_prev", C.c_double),
+        ("residual_last", C.c_double), ("x_norm", C.c_double), ("rel_residual", C.c_double),
+        ("seconds_solve", C.c_double), ("seconds_loop", C.c_double), ("gemv_ms_avg", C.c_double),
+        ("gemv_ms_min", C.c_double), ("gemv_launches", C.c_longlong), ("gemv_bytes", C.c_double),
+        ("reserved", C.c_double * 4),
+    ]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+
+class CgxError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__("libcgx status %d: %s" % (status, msg))
+        self.status = status
+
+
+def build(force=False):
+    """hipcc --offload-arch=gfx950 build of libcgx.so + cgsolver (cross-compiles without a GPU)."""
+    args = ["make", "-C", _PKG, "-s"] + (["-B"] if force else []) + ["all"]
+    subprocess.check_call(args)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libcgx.so.  Raises OSError if it has not been built: there is no fallback path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise OSError("libcgx.so not built (run `make -C conjugate-gradient_amd` or __graft_entry__.build()); "
+                          "the product path has no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        dp = C.POINTER(C.c_double)
+        ip = C.POINTER(C.c_int)
+        vp = C.c_void_p
+        L.cgx_config_init.argtypes = [C.POINTER(Config)]
+        L.cgx_config_init.restype = None
+        L.cgx_comm_unique_id.argtypes = [C.POINTER(C.c_ubyte)]
+        L.cgx_create.argtypes = [C.POINTER(vp), C.POINTER(Config)]
+        L.cgx_destroy.argtypes = [vp]
+        L.cgx_last_error.argtypes = [vp]
+        L.cgx_last_error.restype = C.c_char_p
+        L.cgx_status_string.argtypes = [C.c_int]
+        L.cgx_status_string.restype = C.c_char_p
+        L.cgx_partition.argtypes = [C.c_int, C.c_int, ip, ip]
+        L.cgx_generate_lap2d_matrix.argtypes = [vp, C.c_int]
+        L.cgx_set_matrix_dense.argtypes = [vp, dp, C.c_long, C.c_int]
+        L.cgx_read_matrix.argtypes = [vp, C.c_char_p]
+        L.cgx_init_source_term.argtypes = [vp, C.c_double]
+        L.cgx_set_source_term.argtypes = [vp, dp]
+        L.cgx_set_max_iter.argtypes = [vp, C.c_int]
+        L.cgx_set_tolerance.argtypes = [vp, C.c_double]
+        L.cgx_get_size.argtypes = [vp, ip, ip]
+        L.cgx_solve.argtypes = [vp, dp, C.POINTER(Result)]
+        L.cgx_solve_begin.argtypes = [vp, dp]
+        L.cgx_solve_steps.argtypes = [vp, C.c_int, ip]
+        L.cgx_solve_end.argtypes = [vp, dp, C.POINTER(Result)]
+        L.cgx_probe_gemv.argtypes = [vp, dp, dp, dp]
+        L.cgx_probe_vector_ops.argtypes = [vp, C.c_int, C.c_double, C.c_double, dp, dp, dp, dp, dp]
+        L.cgx_probe_get_matrix_rows.argtypes = [vp, C.c_int, dp, ip, ip]
+        for name in EXPORTS:
+            fn = getattr(L, name)
+            if fn.restype is C.c_int and name not in ("cgx_config_init",):
+                fn.restype = C.c_int
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def partition(n, psize):
+    """CGSolver::partition_matrix (code/MPI/cg.cc:236-268)."""
+    s = (C.c_int * psize)()
+    c = (C.c_int * psize)()
+    st = lib().cgx_partition(n, psize, s, c)
+    if st:
+        raise CgxError(st, "cgx_partition")
+    return list(s), list(c)
+
+
+def comm_unique_id():
+    buf = (C.c_ubyte * UNIQUE_ID_BYTES)()
+    st = lib().cgx_comm_unique_id(buf)
+    if st:
+        raise CgxError(st, lib().cgx_last_error(None).decode())
+    return bytes(buf)
+
+
+class CGSolver:
+    """Python mirror of the reference's CGSolver (same member names) over the C ABI.
+
+    read_matrix / generate_lap2d_matrix / init_source_term / set_max_iter / tolerance / solve / m / n
+    keep the reference's meaning; the constructor takes what `srun -n P` and MPI_Init gave the reference.
+    """
+
+    def __init__(self, comm_mode=COMM_SELF, nranks=1, rank=0, device=0, unique_id=None, gemv_variant=0,
+                 lda_pad=-1, check_every=0, profile_gemv=False):
+        L = lib()
+        cfg = Config()
+        L.cgx_config_init(C.byref(cfg))
+        cfg.comm_mode = comm_mode
+        cfg.nranks = nranks
+        cfg.rank = rank
+        cfg.device = device
+        cfg.gemv_variant = gemv_variant
+        cfg.lda_pad = lda_pad
+        cfg.check_every = check_every
+        cfg.profile_gemv = 1 if profile_gemv else 0
+        if unique_id is not None:
+            assert len(unique_id) == UNIQUE_ID_BYTES
+            C.memmove(cfg.unique_id, bytes(unique_id), UNIQUE_ID_BYTES)
+        self._h = C.c_void_p()
+        st = L.cgx_create(C.byref(self._h), C.byref(cfg))
+        if st:
+            self._h = C.c_void_p()
+            raise CgxError(st, L.cgx_last_error(None).decode())
+        self.nranks = nranks
+        self.rank = rank
+
+    # -- plumbing -------------------------------------------------------------------------------
+    def _check(self, st):
+        if st:
+            raise CgxError(st, lib().cgx_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            lib().cgx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- reference interface --------------------------------------------------------------------
+    def generate_lap2d_matrix(self, size):
+        self._check(lib().cgx_generate_lap2d_matrix(self._h, int(size)))
+
+    def read_matrix(self, filename):
+        self._check(lib().cgx_read_matrix(self._h, os.fsencode(filename)))
+
+    def set_matrix_dense(self, A):
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        assert A.ndim == 2 and A.shape[0] == A.shape[1]
+        self._check(lib().cgx_set_matrix_dense(self._h, _dp(A), A.shape[1], A.shape[0]))
+
+    def init_source_term(self, h):
+        self._check(lib().cgx_init_source_term(self._h, float(h)))
+
+    def set_source_term(self, b):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        self._check(lib().cgx_set_source_term(self._h, _dp(b)))
+
+    def set_max_iter(self, max_iter):
+        self._check(lib().cgx_set_max_iter(self._h, int(max_iter)))
+
+    def tolerance(self, tol):
+        self._check(lib().cgx_set_tolerance(self._h, float(tol)))
+
+    def _size(self):
+        m = C.c_int()
+        n = C.c_int()
+        self._check(lib().cgx_get_size(self._h, C.byref(m), C.byref(n)))
+        return m.value, n.value
+
+    def m(self):
+        return self._size()[0]
+
+    def n(self):
+        return self._size()[1]
+
+    def solve(self, x):
+        """x: float64 array of length n, initial guess in / solution out.  Returns the result dict."""
+        assert x.dtype == np.float64 and x.flags["C_CONTIGUOUS"] and x.size == self.n()
+        res = Result()
+        self._check(lib().cgx_solve(self._h, _dp(x), C.byref(res)))
+        return res.as_dict()
+
+    # -- stepping interface used by bench.py ----------------------------------------------------------
+    def solve_begin(self, x0):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        self._check(lib().cgx_solve_begin(self._h, _dp(x0)))
+
+    def solve_steps(self, nsteps):
+        done = C.c_int()
+        self._check(lib().cgx_solve_steps(self._h, int(nsteps), C.byref(done)))
+        return bool(done.value)
+
+    def solve_end(self, x=None):
+        res = Result()
+        xp = _dp(x) if x is not None else None
+        self._check(lib().cgx_solve_end(self._h, xp, C.byref(res)))
+        return res.as_dict()
+
+    # -- kernel probes -------------------------------------------------------------------------------
+    def probe_gemv(self, p):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        y = np.zeros(self.n(), dtype=np.float64)
+        pap = C.c_double()
+        self._check(lib().cgx_probe_gemv(self._h, _dp(p), _dp(y), C.byref(pap)))
+        return y, pap.value
+
+    def probe_vector_ops(self, alpha, beta, x, r, p, Ap):
+        x, r, p = (np.array(v, dtype=np.float64, copy=True) for v in (x, r, p))
+        Ap = np.ascontiguousarray(Ap, dtype=np.float64)
+        rr = C.c_double()
+        self._check(lib().cgx_probe_vector_ops(self._h, x.size, alpha, beta, _dp(x), _dp(r), _dp(p), _dp(Ap),
+                                               C.byref(rr)))
+        return x, r, p, rr.value
+
+    def probe_matrix_rows(self, local_shard=0):
+        row0 = C.c_int()
+        rows = C.c_int()
+        self._check(lib().cgx_probe_get_matrix_rows(self._h, local_shard, None, C.byref(row0), C.byref(rows)))
+        A = np.zeros((rows.value, self.n()), dtype=np.float64)
+        if rows.value:
+            self._check(lib().cgx_probe_get_matrix_rows(self._h, local_shard, _dp(A), C.byref(row0), C.byref(rows)))
+        return A, row0.value

@@ -1,0 +1,939 @@
+// cgx_solver.cpp -- context, row-block shards, collectives and the CG driver loop behind include/cgx.h.
+//
+// Reference path: CGSolver::solve, code/MPI/cg.cc:38-156 (citations are file:line under /root/reference).
+// Design (MI355X-first, not a translation):
+//   * the row block of A, b, x, r, Ap and the replicated p live in HBM for the life of the problem;
+//   * rsold/rsnew/alpha/beta and the convergence flag stay on the device (cgx::Scalars): the host only
+//     enqueues kernels and polls one int every `check_every` iterations, so the stream never drains;
+//   * after convergence every kernel of the remaining enqueued iterations exits at its first
+//     instruction, which reproduces the reference's `break` (cg.cc:120-121) exactly;
+//   * MPI_Allreduce of one double  -> all-gather of kSlots doubles per rank + rank-ordered sum inside
+//     the consuming kernel (bit-identical on all ranks); MPI_Allgatherv of p -> in-place ncclAllGather
+//     (or grouped ncclBroadcast when N % P != 0) straight into the replicated p that K1 reads.
+#include "../../include/cgx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cctype>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "cgx_kernels.h"
+#include "cgx_rccl.h"
+
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
+
+using cgx::Scalars;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+double wall_now()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+struct Shard {
+    int rank = 0;
+    int row0 = 0;
+    int rows = 0;
+    double *A = nullptr;         // rows x lda, row-major, pad columns zero
+    double *b = nullptr;         // rows
+    double *x = nullptr;         // rows
+    double *r = nullptr;         // rows
+    double *Ap = nullptr;        // rows
+    double *p_full = nullptr;    // lda doubles: the replicated p (cg.cc:57); this shard's slice is p_full + row0
+    double *partials = nullptr;  // per-workgroup partial sums
+    Scalars *sc = nullptr;
+    double *gathered = nullptr;  // kMaxRanks * kSlots doubles
+    cgx::GemvPlan plan{};
+    int npartials = 0;
+};
+
+}  // namespace
+
+struct cgx_ctx {
+    cgx_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int nranks = 1;
+    int m = 0, n = 0;
+    long lda = 0;
+    int max_iter = 0;
+    double tol = 1e-10;   // m_tolerance, code/MPI/cg.hh:56
+    std::vector<int> start_rows, num_rows;
+    std::vector<Shard> shards;   // 1 (SELF / RCCL) or nranks (LOOPBACK)
+    std::vector<double> b_host;
+    bool have_matrix = false, have_b = false;
+
+    // RCCL
+    const cgx::RcclApi *rccl = nullptr;
+    ncclComm_t comm = nullptr;
+    bool even_partition = true;
+
+    // loopback pointer tables (device)
+    double **d_gathered_ptrs = nullptr;
+    Scalars **d_scalar_ptrs = nullptr;
+
+    // solve state
+    bool in_solve = false;
+    int k = 0;              // iterations enqueued so far
+    bool done = false;
+    int k_final = 0;
+    int *h_flags = nullptr;   // pinned: 2 slots x {done, k_final}
+    hipEvent_t flag_ev[2] = {nullptr, nullptr};
+    double t_begin = 0, t_loop = 0;
+
+    // K1 timing
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    double gemv_ms_sum = 0, gemv_ms_min = 0;
+    long long gemv_launches = 0;
+
+    std::string err;
+};
+
+namespace {
+
+cgx_status fail(cgx_ctx *ctx, cgx_status st, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    else g_create_error = msg;
+    return st;
+}
+
+#define HIP_TRY(ctx, call)                                                                              \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            cgx_status st_ = (e_ == hipErrorOutOfMemory) ? CGX_ERR_OOM                                  \
+                             : (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? CGX_ERR_NO_DEVICE \
+                                                                                       : CGX_ERR_HIP;   \
+            return fail(ctx, st_, std::string(#call) + ": " + hipGetErrorString(e_));                   \
+        }                                                                                               \
+    } while (0)
+
+#define NCCL_TRY(ctx, call)                                                                             \
+    do {                                                                                                \
+        ncclResult_t r_ = (call);                                                                       \
+        if (r_ != ncclSuccess)                                                                          \
+            return fail(ctx, CGX_ERR_RCCL, std::string(#call) + ": " + (ctx)->rccl->GetErrorString(r_)); \
+    } while (0)
+
+#define CGX_TRY(call)                      \
+    do {                                   \
+        cgx_status s_ = (call);            \
+        if (s_ != CGX_OK) return s_;       \
+    } while (0)
+
+void partition_rows(int N, int psize, int *start_rows, int *num_rows)
+{
+    // CGSolver::partition_matrix, code/MPI/cg.cc:236-268: floor(N/psize) rows per rank, remainder on the last.
+    const int n_loc = (psize > 0) ? N / psize : N;
+    int i0 = 0;
+    for (int r = 0; r + 1 < psize; ++r) {
+        start_rows[r] = i0;
+        num_rows[r] = n_loc;
+        i0 += n_loc;
+    }
+    start_rows[psize - 1] = i0;
+    num_rows[psize - 1] = N - i0;
+}
+
+void free_shard(Shard &s)
+{
+    (void)hipFree(s.A);
+    (void)hipFree(s.b);
+    (void)hipFree(s.x);
+    (void)hipFree(s.r);
+    (void)hipFree(s.Ap);
+    (void)hipFree(s.p_full);
+    (void)hipFree(s.partials);
+    (void)hipFree(s.sc);
+    (void)hipFree(s.gathered);
+    s = Shard{};
+}
+
+void free_problem(cgx_ctx *ctx)
+{
+    for (auto &s : ctx->shards) free_shard(s);
+    ctx->shards.clear();
+    (void)hipFree(ctx->d_gathered_ptrs);
+    (void)hipFree(ctx->d_scalar_ptrs);
+    ctx->d_gathered_ptrs = nullptr;
+    ctx->d_scalar_ptrs = nullptr;
+    ctx->have_matrix = ctx->have_b = false;
+    ctx->in_solve = false;
+}
+
+long default_lda(const cgx_ctx *ctx, int n)
+{
+    long lda = ((long)n + 15) / 16 * 16;   // every row starts on a 128-B line
+    int pad = ctx->cfg.lda_pad;
+    if (pad < 0) {
+        const char *e = getenv("CGX_LDA_PAD");
+        pad = e ? atoi(e) : 0;
+    }
+    if (pad > 0) lda += (pad + 1) / 2 * 2;
+    return lda;
+}
+
+// Allocate the shards for an n x n problem (matrix contents are filled by the caller).
+cgx_status setup_problem(cgx_ctx *ctx, int n)
+{
+    if (n <= 0) return fail(ctx, CGX_ERR_BAD_ARG, "matrix size must be positive");
+    free_problem(ctx);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->m = ctx->n = n;
+    ctx->max_iter = n;   // m_maxIter = size, code/MPI/cg.cc:172
+    ctx->lda = default_lda(ctx, n);
+    ctx->start_rows.assign(ctx->nranks, 0);
+    ctx->num_rows.assign(ctx->nranks, 0);
+    partition_rows(n, ctx->nranks, ctx->start_rows.data(), ctx->num_rows.data());
+    ctx->even_partition = true;
+    for (int q = 0; q < ctx->nranks; ++q)
+        if (ctx->num_rows[q] != ctx->num_rows[0]) ctx->even_partition = false;
+
+    int variant = ctx->cfg.gemv_variant;
+    if (variant <= 0) {
+        const char *e = getenv("CGX_GEMV_VARIANT");
+        if (e) variant = atoi(e);
+    }
+    const int nlocal = (ctx->cfg.comm_mode == CGX_COMM_LOOPBACK) ? ctx->nranks : 1;
+    ctx->shards.resize(nlocal);
+    for (int i = 0; i < nlocal; ++i) {
+        Shard &s = ctx->shards[i];
+        s.rank = (ctx->cfg.comm_mode == CGX_COMM_RCCL) ? ctx->cfg.rank : i;
+        s.row0 = ctx->start_rows[s.rank];
+        s.rows = ctx->num_rows[s.rank];
+        s.plan = cgx::plan_gemv(variant, s.rows, (int)ctx->lda);
+        const size_t rows_alloc = (size_t)std::max(s.rows, 1);
+        s.npartials = std::max(s.plan.grid, 3 * cgx::update_xr_grid(s.rows)) + 8;
+        HIP_TRY(ctx, hipMalloc(&s.A, rows_alloc * (size_t)ctx->lda * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&s.b, rows_alloc * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&s.x, rows_alloc * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&s.r, rows_alloc * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&s.Ap, rows_alloc * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&s.p_full, (size_t)ctx->lda * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&s.partials, (size_t)s.npartials * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&s.sc, sizeof(Scalars)));
+        HIP_TRY(ctx, hipMalloc(&s.gathered, (size_t)cgx::kMaxRanks * cgx::kSlots * sizeof(double)));
+        HIP_TRY(ctx, hipMemsetAsync(s.p_full, 0, (size_t)ctx->lda * sizeof(double), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(s.partials, 0, (size_t)s.npartials * sizeof(double), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(s.sc, 0, sizeof(Scalars), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(s.gathered, 0, (size_t)cgx::kMaxRanks * cgx::kSlots * sizeof(double), ctx->stream));
+    }
+    if (ctx->cfg.comm_mode == CGX_COMM_LOOPBACK) {
+        std::vector<double *> gp(nlocal);
+        std::vector<Scalars *> sp(nlocal);
+        for (int i = 0; i < nlocal; ++i) {
+            gp[i] = ctx->shards[i].gathered;
+            sp[i] = ctx->shards[i].sc;
+        }
+        HIP_TRY(ctx, hipMalloc(&ctx->d_gathered_ptrs, nlocal * sizeof(double *)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_scalar_ptrs, nlocal * sizeof(Scalars *)));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_gathered_ptrs, gp.data(), nlocal * sizeof(double *), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_scalar_ptrs, sp.data(), nlocal * sizeof(Scalars *), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CGX_OK;
+}
+
+// ---- collectives ---------------------------------------------------------------------------------
+
+// Scalars: every shard contributes sc->local[kSlots]; afterwards every shard's gathered[] holds all of them.
+// Replaces MPI_Allreduce (cg.cc:92,106,117).  In SELF mode the consumers read sc->local directly.
+const double *gathered_ptr(const cgx_ctx *ctx, const Shard &s)
+{
+    return (ctx->cfg.comm_mode == CGX_COMM_SELF) ? s.sc->local : s.gathered;
+}
+
+cgx_status gather_scalars(cgx_ctx *ctx)
+{
+    switch (ctx->cfg.comm_mode) {
+    case CGX_COMM_SELF:
+        return CGX_OK;
+    case CGX_COMM_LOOPBACK:
+        HIP_TRY(ctx, cgx::launch_loopback_gather(ctx->d_gathered_ptrs, ctx->d_scalar_ptrs, ctx->nranks, ctx->stream));
+        return CGX_OK;
+    default: {
+        Shard &s = ctx->shards[0];
+        NCCL_TRY(ctx, ctx->rccl->AllGather(s.sc->local, s.gathered, cgx::kSlots, ncclDouble, ctx->comm, ctx->stream));
+        return CGX_OK;
+    }
+    }
+}
+
+// Replicated vector: every shard's slice [row0,row0+rows) of its own p_full is current; afterwards all of
+// p_full is.  Replaces MPI_Allgatherv (cg.cc:87-88,135-136) and, for x, MPI_Gatherv (cg.cc:140-142).
+cgx_status gather_p(cgx_ctx *ctx)
+{
+    switch (ctx->cfg.comm_mode) {
+    case CGX_COMM_SELF:
+        return CGX_OK;
+    case CGX_COMM_LOOPBACK:
+        for (auto &dst : ctx->shards)
+            for (auto &src : ctx->shards)
+                if (dst.rank != src.rank && src.rows > 0)
+                    HIP_TRY(ctx, hipMemcpyAsync(dst.p_full + src.row0, src.p_full + src.row0,
+                                                (size_t)src.rows * sizeof(double), hipMemcpyDeviceToDevice,
+                                                ctx->stream));
+        return CGX_OK;
+    default: {
+        Shard &s = ctx->shards[0];
+        if (ctx->even_partition) {
+            NCCL_TRY(ctx, ctx->rccl->AllGather(s.p_full + s.row0, s.p_full, (size_t)s.rows, ncclDouble, ctx->comm,
+                                               ctx->stream));
+        } else {
+            // N % P != 0: the last rank owns more rows (cg.cc:265-266).  One fused group of in-place broadcasts.
+            NCCL_TRY(ctx, ctx->rccl->GroupStart());
+            for (int q = 0; q < ctx->nranks; ++q) {
+                if (ctx->num_rows[q] <= 0) continue;
+                double *seg = s.p_full + ctx->start_rows[q];
+                ncclResult_t r = ctx->rccl->Broadcast(seg, seg, (size_t)ctx->num_rows[q], ncclDouble, q, ctx->comm,
+                                                      ctx->stream);
+                if (r != ncclSuccess) {
+                    (void)ctx->rccl->GroupEnd();
+                    return fail(ctx, CGX_ERR_RCCL, std::string("ncclBroadcast: ") + ctx->rccl->GetErrorString(r));
+                }
+            }
+            NCCL_TRY(ctx, ctx->rccl->GroupEnd());
+        }
+        return CGX_OK;
+    }
+    }
+}
+
+// ---- K1 with optional event bracketing -----------------------------------------------------------
+cgx_status take_event(cgx_ctx *ctx, hipEvent_t *out)
+{
+    if (ctx->ev_used == ctx->ev_pool.size()) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->ev_pool.push_back(e);
+    }
+    *out = ctx->ev_pool[ctx->ev_used++];
+    return CGX_OK;
+}
+
+cgx_status run_gemv(cgx_ctx *ctx, Shard &s, const int *done, bool timed)
+{
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timed) {
+        CGX_TRY(take_event(ctx, &e0));
+        CGX_TRY(take_event(ctx, &e1));
+        HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+    }
+    HIP_TRY(ctx, cgx::launch_gemv(s.plan, s.A, ctx->lda, s.rows, s.p_full, s.p_full + s.row0, s.Ap, s.partials, done,
+                                  ctx->stream));
+    if (timed) HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+    return CGX_OK;
+}
+
+// Fold the recorded event pairs into the running K1 statistics (call after a stream sync).
+cgx_status harvest_gemv_events(cgx_ctx *ctx)
+{
+    for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[i], ctx->ev_pool[i + 1]));
+        ctx->gemv_ms_sum += ms;
+        if (ctx->gemv_launches == 0 || ms < ctx->gemv_ms_min) ctx->gemv_ms_min = ms;
+        ctx->gemv_launches++;
+    }
+    ctx->ev_used = 0;
+    return CGX_OK;
+}
+
+// ---- one body of the loop cg.cc:96-137 -------------------------------------------------------------
+cgx_status enqueue_iteration(cgx_ctx *ctx, int k)
+{
+    const int par = k & 1;
+    const bool timed = ctx->cfg.profile_gemv != 0;
+    hipStream_t st = ctx->stream;
+    for (auto &s : ctx->shards) CGX_TRY(run_gemv(ctx, s, &s.sc->done, timed));                       // cg.cc:100-102
+    for (auto &s : ctx->shards)
+        HIP_TRY(ctx, cgx::launch_reduce_partials(s.partials, s.plan.grid, &s.sc->local[cgx::kSlotConj], &s.sc->done,
+                                                 st));                                               // cg.cc:105
+    CGX_TRY(gather_scalars(ctx));                                                                    // cg.cc:106
+    for (auto &s : ctx->shards)
+        HIP_TRY(ctx, cgx::launch_update_xr(s.rows, s.p_full + s.row0, s.Ap, s.x, s.r, s.sc, par, gathered_ptr(ctx, s),
+                                           ctx->nranks, s.partials, st));                            // cg.cc:107-116
+    for (auto &s : ctx->shards)
+        HIP_TRY(ctx, cgx::launch_reduce_partials(s.partials, cgx::update_xr_grid(s.rows), &s.sc->local[cgx::kSlotRr],
+                                                 &s.sc->done, st));
+    CGX_TRY(gather_scalars(ctx));                                                                    // cg.cc:117
+    for (auto &s : ctx->shards)
+        HIP_TRY(ctx, cgx::launch_update_p(s.rows, s.r, s.p_full + s.row0, s.sc, par, k, ctx->tol, gathered_ptr(ctx, s),
+                                          ctx->nranks, st));                                         // cg.cc:120-132
+    CGX_TRY(gather_p(ctx));                                                                          // cg.cc:135-136
+    return CGX_OK;
+}
+
+cgx_status read_flags_sync(cgx_ctx *ctx)
+{
+    Shard &s = ctx->shards[0];
+    int flags[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(flags, &s.sc->done, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->done = flags[0] != 0;
+    ctx->k_final = flags[1];
+    return CGX_OK;
+}
+
+}  // namespace
+
+// =====================================================================================================
+// C ABI
+// =====================================================================================================
+extern "C" {
+
+void cgx_config_init(cgx_config *cfg)
+{
+    if (!cfg) return;
+    memset(cfg, 0, sizeof *cfg);
+    cfg->struct_version = CGX_VERSION;
+    cfg->comm_mode = CGX_COMM_SELF;
+    cfg->device = 0;
+    cfg->rank = 0;
+    cfg->nranks = 1;
+    cfg->lda_pad = -1;
+}
+
+const char *cgx_status_string(cgx_status s)
+{
+    switch (s) {
+    case CGX_OK: return "ok";
+    case CGX_ERR_BAD_ARG: return "bad argument";
+    case CGX_ERR_IO: return "i/o error";
+    case CGX_ERR_HIP: return "HIP error";
+    case CGX_ERR_RCCL: return "RCCL error";
+    case CGX_ERR_OOM: return "out of memory";
+    case CGX_ERR_NO_DEVICE: return "no usable GPU (libcgx has no CPU fallback)";
+    case CGX_ERR_UNSUPPORTED: return "unsupported input";
+    }
+    return "unknown";
+}
+
+const char *cgx_last_error(const cgx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+cgx_status cgx_partition(int n, int psize, int *start_rows, int *num_rows)
+{
+    if (n < 0 || psize <= 0 || !start_rows || !num_rows) return CGX_ERR_BAD_ARG;
+    partition_rows(n, psize, start_rows, num_rows);
+    return CGX_OK;
+}
+
+cgx_status cgx_comm_unique_id(unsigned char out[CGX_UNIQUE_ID_BYTES])
+{
+    static_assert(sizeof(ncclUniqueId) == CGX_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    if (!out) return CGX_ERR_BAD_ARG;
+    std::string err;
+    const cgx::RcclApi *api = cgx::rccl_api(&err);
+    if (!api) return fail(nullptr, CGX_ERR_RCCL, err);
+    ncclUniqueId id;
+    ncclResult_t r = api->GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, CGX_ERR_RCCL, std::string("ncclGetUniqueId: ") + api->GetErrorString(r));
+    memcpy(out, &id, CGX_UNIQUE_ID_BYTES);
+    return CGX_OK;
+}
+
+cgx_status cgx_create(cgx_ctx **out, const cgx_config *cfg_in)
+{
+    if (!out) return fail(nullptr, CGX_ERR_BAD_ARG, "cgx_create: out is null");
+    *out = nullptr;
+    cgx_config cfg;
+    if (cfg_in) cfg = *cfg_in;
+    else cgx_config_init(&cfg);
+    if (cfg.struct_version != CGX_VERSION) return fail(nullptr, CGX_ERR_BAD_ARG, "cgx_config.struct_version mismatch");
+    if (cfg.nranks <= 0) cfg.nranks = 1;
+    if (cfg.comm_mode == CGX_COMM_SELF && cfg.nranks != 1)
+        return fail(nullptr, CGX_ERR_BAD_ARG, "CGX_COMM_SELF requires nranks == 1");
+    if (cfg.comm_mode == CGX_COMM_LOOPBACK && cfg.nranks > 16)
+        return fail(nullptr, CGX_ERR_BAD_ARG, "CGX_COMM_LOOPBACK supports at most 16 logical shards");
+    if (cfg.comm_mode == CGX_COMM_RCCL && (cfg.rank < 0 || cfg.rank >= cfg.nranks || cfg.nranks > cgx::kMaxRanks))
+        return fail(nullptr, CGX_ERR_BAD_ARG, "CGX_COMM_RCCL: rank out of range or nranks > 64");
+    if (cfg.comm_mode < CGX_COMM_SELF || cfg.comm_mode > CGX_COMM_RCCL)
+        return fail(nullptr, CGX_ERR_BAD_ARG, "unknown comm_mode");
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, CGX_ERR_NO_DEVICE,
+                    std::string("no HIP device visible (") + hipGetErrorString(e) + "); libcgx has no CPU fallback");
+    if (cfg.device < 0 || cfg.device >= ndev) return fail(nullptr, CGX_ERR_NO_DEVICE, "device ordinal out of range");
+
+    cgx_ctx *ctx = new (std::nothrow) cgx_ctx();
+    if (!ctx) return fail(nullptr, CGX_ERR_OOM, "host allocation failed");
+    ctx->cfg = cfg;
+    ctx->device = cfg.device;
+    ctx->nranks = cfg.nranks;
+    if (ctx->cfg.check_every <= 0) ctx->cfg.check_every = 16;
+
+    auto bail = [&](cgx_status st) {
+        g_create_error = ctx->err;
+        cgx_destroy(ctx);
+        return st;
+    };
+    if (hipSetDevice(ctx->device) != hipSuccess) {
+        ctx->err = "hipSetDevice failed";
+        return bail(CGX_ERR_NO_DEVICE);
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) {
+        ctx->err = "hipGetDeviceProperties failed";
+        return bail(CGX_ERR_HIP);
+    }
+    if (!strstr(prop.gcnArchName, "gfx950") && !getenv("CGX_ALLOW_ANY_ARCH")) {
+        ctx->err = std::string("device is ") + prop.gcnArchName + ", libcgx is built for gfx950 (MI355X) only";
+        return bail(CGX_ERR_NO_DEVICE);
+    }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        ctx->err = "hipStreamCreate failed";
+        return bail(CGX_ERR_HIP);
+    }
+    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_flags), 4 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->flag_ev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->flag_ev[1], hipEventDisableTiming) != hipSuccess) {
+        ctx->err = "pinned flag / event allocation failed";
+        return bail(CGX_ERR_HIP);
+    }
+    if (cfg.comm_mode == CGX_COMM_RCCL) {
+        std::string err;
+        ctx->rccl = cgx::rccl_api(&err);
+        if (!ctx->rccl) {
+            ctx->err = err;
+            return bail(CGX_ERR_RCCL);
+        }
+        ncclUniqueId id;
+        memcpy(&id, cfg.unique_id, CGX_UNIQUE_ID_BYTES);
+        ncclResult_t r = ctx->rccl->CommInitRank(&ctx->comm, cfg.nranks, id, cfg.rank);
+        if (r != ncclSuccess) {
+            ctx->err = std::string("ncclCommInitRank: ") + ctx->rccl->GetErrorString(r);
+            ctx->comm = nullptr;
+            return bail(CGX_ERR_RCCL);
+        }
+    }
+    *out = ctx;
+    return CGX_OK;
+}
+
+cgx_status cgx_destroy(cgx_ctx *ctx)
+{
+    if (!ctx) return CGX_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_problem(ctx);
+    if (ctx->comm && ctx->rccl) (void)ctx->rccl->CommDestroy(ctx->comm);
+    for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+    for (auto e : ctx->flag_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return CGX_OK;
+}
+
+cgx_status cgx_get_size(const cgx_ctx *ctx, int *m, int *n)
+{
+    if (!ctx) return CGX_ERR_BAD_ARG;
+    if (m) *m = ctx->m;
+    if (n) *n = ctx->n;
+    return CGX_OK;
+}
+
+cgx_status cgx_set_max_iter(cgx_ctx *ctx, int max_iter)
+{
+    if (!ctx) return CGX_ERR_BAD_ARG;
+    ctx->max_iter = max_iter;   // the reference does not validate either (cg.cc:204-216)
+    return CGX_OK;
+}
+
+cgx_status cgx_set_tolerance(cgx_ctx *ctx, double tol)
+{
+    if (!ctx) return CGX_ERR_BAD_ARG;
+    ctx->tol = tol;
+    return CGX_OK;
+}
+
+// ---- generate_lap2d_matrix, cg.cc:159-188 ----------------------------------------------------------
+cgx_status cgx_generate_lap2d_matrix(cgx_ctx *ctx, int size)
+{
+    if (!ctx) return CGX_ERR_BAD_ARG;
+    CGX_TRY(setup_problem(ctx, size));
+    for (auto &s : ctx->shards)
+        HIP_TRY(ctx, cgx::launch_generate_lap2d(s.A, ctx->lda, size, s.row0, s.rows, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_matrix = true;
+    return CGX_OK;
+}
+
+// ---- read_matrix with a caller-supplied dense matrix (cg.cu:307-321 after Matrix::read) ---------
+cgx_status cgx_set_matrix_dense(cgx_ctx *ctx, const double *A, long lda_host, int n)
+{
+    if (!ctx || !A || lda_host < n) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_set_matrix_dense: bad argument");
+    CGX_TRY(setup_problem(ctx, n));
+    for (auto &s : ctx->shards) {
+        if (s.rows <= 0) continue;
+        HIP_TRY(ctx, hipMemsetAsync(s.A, 0, (size_t)s.rows * ctx->lda * sizeof(double), ctx->stream));
+        HIP_TRY(ctx, hipMemcpy2DAsync(s.A, (size_t)ctx->lda * sizeof(double), A + (size_t)s.row0 * lda_host,
+                                      (size_t)lda_host * sizeof(double), (size_t)n * sizeof(double), (size_t)s.rows,
+                                      hipMemcpyHostToDevice, ctx->stream));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_matrix = true;
+    return CGX_OK;
+}
+
+// ---- MatrixCOO::read + Matrix::read, matrix_coo.cc:7-60 and matrix.cc:6-22 -------------------------
+cgx_status cgx_read_matrix(cgx_ctx *ctx, const char *path)
+{
+    if (!ctx || !path) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_read_matrix: bad argument");
+    FILE *f = fopen(path, "r");
+    if (!f) return fail(ctx, CGX_ERR_IO, std::string("Could not open matrix: ") + path);   // matrix_coo.cc:14-17
+    struct Closer {
+        FILE *f;
+        ~Closer() { fclose(f); }
+    } closer{f};
+
+    char line[2048];
+    if (!fgets(line, sizeof line, f)) return fail(ctx, CGX_ERR_IO, "Could not process Matrix Market banner.");
+    char tok[5][64] = {{0}};
+    if (sscanf(line, "%63s %63s %63s %63s %63s", tok[0], tok[1], tok[2], tok[3], tok[4]) != 5 ||
+        strcmp(tok[0], "%%MatrixMarket") != 0)
+        return fail(ctx, CGX_ERR_IO, "Could not process Matrix Market banner.");   // matrix_coo.cc:19-22
+    for (int t = 1; t < 5; ++t)
+        for (char *c = tok[t]; *c; ++c) *c = (char)tolower((unsigned char)*c);       // mmio.c lower-cases the tokens
+    if (strcmp(tok[1], "matrix") != 0 || strcmp(tok[2], "coordinate") != 0)
+        return fail(ctx, CGX_ERR_UNSUPPORTED, std::string("Sorry, this application does not support Market Market type: [") +
+                                                  tok[1] + " " + tok[2] + " " + tok[3] + " " + tok[4] + "]");   // matrix_coo.cc:25-29
+    // The reference parses every entry as "%d %d %lg" whatever the field (matrix_coo.cc:48); fields without
+    // one real value per entry would be silently misread there and are rejected here.
+    if (strcmp(tok[3], "real") != 0 && strcmp(tok[3], "integer") != 0 && strcmp(tok[3], "double") != 0)
+        return fail(ctx, CGX_ERR_UNSUPPORTED, std::string("Matrix Market field not supported: ") + tok[3]);
+    const bool is_sym = strcmp(tok[4], "symmetric") == 0;                             // matrix_coo.cc:43
+    if (!is_sym && strcmp(tok[4], "general") != 0)
+        return fail(ctx, CGX_ERR_UNSUPPORTED, std::string("Matrix Market symmetry not supported: ") + tok[4]);
+
+    int m = 0, n = 0, nz = 0;
+    for (;;) {   // size line after the % comments, mmio.c:198-206
+        if (!fgets(line, sizeof line, f)) return fail(ctx, CGX_ERR_IO, "Matrix Market size line missing");
+        if (line[0] == '%') continue;
+        if (sscanf(line, "%d %d %d", &m, &n, &nz) == 3) break;
+    }
+    if (m <= 0 || n <= 0 || nz < 0 || m != n)
+        return fail(ctx, CGX_ERR_UNSUPPORTED, "CG needs a square matrix with positive size");
+    CGX_TRY(setup_problem(ctx, n));
+
+    // Keep only the entries (and mirrored entries) that land in a local row block; a later entry for the
+    // same (i,j) overrides an earlier one, as the sequential assignment in matrix.cc:12-21 does.
+    struct Coo {
+        std::vector<int> I, J;
+        std::vector<double> a;
+        std::unordered_map<unsigned long long, size_t> pos;
+    };
+    std::vector<Coo> coo(ctx->shards.size());
+    auto put = [&](int i, int j, double v) {
+        for (size_t si = 0; si < ctx->shards.size(); ++si) {
+            const Shard &s = ctx->shards[si];
+            if (i < s.row0 || i >= s.row0 + s.rows) continue;
+            Coo &c = coo[si];
+            const unsigned long long key = (unsigned long long)(unsigned)i << 32 | (unsigned)j;
+            auto it = c.pos.find(key);
+            if (it != c.pos.end()) c.a[it->second] = v;
+            else {
+                c.pos.emplace(key, c.a.size());
+                c.I.push_back(i);
+                c.J.push_back(j);
+                c.a.push_back(v);
+            }
+        }
+    };
+    for (int z = 0; z < nz; ++z) {
+        int I, J;
+        double a;
+        if (fscanf(f, "%d %d %lg", &I, &J, &a) != 3)
+            return fail(ctx, CGX_ERR_IO, "Matrix Market entry " + std::to_string(z) + " unreadable");
+        I--; J--;                                                                     // matrix_coo.cc:49-50
+        if (I < 0 || I >= m || J < 0 || J >= n) return fail(ctx, CGX_ERR_IO, "Matrix Market index out of range");
+        put(I, J, a);                                                                 // matrix.cc:17
+        if (is_sym) put(J, I, a);                                                     // matrix.cc:18-20
+    }
+    for (size_t si = 0; si < ctx->shards.size(); ++si) {
+        Shard &s = ctx->shards[si];
+        Coo &c = coo[si];
+        if (s.rows <= 0) continue;
+        HIP_TRY(ctx, hipMemsetAsync(s.A, 0, (size_t)s.rows * ctx->lda * sizeof(double), ctx->stream));  // Matrix::resize zero-fills
+        const size_t cnt = c.a.size();
+        if (!cnt) continue;
+        int *dI = nullptr, *dJ = nullptr;
+        double *da = nullptr;
+        HIP_TRY(ctx, hipMalloc(&dI, cnt * sizeof(int)));
+        HIP_TRY(ctx, hipMalloc(&dJ, cnt * sizeof(int)));
+        HIP_TRY(ctx, hipMalloc(&da, cnt * sizeof(double)));
+        HIP_TRY(ctx, hipMemcpyAsync(dI, c.I.data(), cnt * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(dJ, c.J.data(), cnt * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(da, c.a.data(), cnt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, cgx::launch_scatter_coo(s.A, ctx->lda, s.row0, dI, dJ, da, (long)cnt, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(dI);
+        (void)hipFree(dJ);
+        (void)hipFree(da);
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_matrix = true;
+    return CGX_OK;
+}
+
+// ---- init_source_term, cg.cc:218-234 ----------------------------------------------------------------
+cgx_status cgx_set_source_term(cgx_ctx *ctx, const double *b)
+{
+    if (!ctx || !b) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_set_source_term: bad argument");
+    if (ctx->n <= 0 || ctx->shards.empty()) return fail(ctx, CGX_ERR_BAD_ARG, "set the matrix before the source term");
+    ctx->b_host.assign(b, b + ctx->n);
+    for (auto &s : ctx->shards)
+        if (s.rows > 0)
+            HIP_TRY(ctx, hipMemcpyAsync(s.b, ctx->b_host.data() + s.row0, (size_t)s.rows * sizeof(double),
+                                        hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->have_b = true;
+    return CGX_OK;
+}
+
+cgx_status cgx_init_source_term(cgx_ctx *ctx, double h)
+{
+    if (!ctx) return CGX_ERR_BAD_ARG;
+    if (ctx->n <= 0) return fail(ctx, CGX_ERR_BAD_ARG, "set the matrix before the source term");
+    // Evaluated on the host with libm, in the reference's expression order, so b is bit-identical (cg.cc:230-231).
+    std::vector<double> b((size_t)ctx->n);
+    for (int i = 0; i < ctx->n; i++)
+        b[i] = -2. * i * M_PI * M_PI * std::sin(10. * M_PI * i * h) * std::sin(10. * M_PI * i * h);
+    return cgx_set_source_term(ctx, b.data());
+}
+
+// ---- solve, cg.cc:38-156 -----------------------------------------------------------------------------
+cgx_status cgx_solve_begin(cgx_ctx *ctx, const double *x0)
+{
+    if (!ctx || !x0) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_solve_begin: bad argument");
+    if (!ctx->have_matrix || !ctx->have_b) return fail(ctx, CGX_ERR_BAD_ARG, "matrix and source term must be set before solve");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->t_begin = wall_now();
+    ctx->t_loop = 0;
+    ctx->k = 0;
+    ctx->done = false;
+    ctx->k_final = 0;
+    ctx->ev_used = 0;
+    ctx->gemv_ms_sum = ctx->gemv_ms_min = 0;
+    ctx->gemv_launches = 0;
+    hipStream_t st = ctx->stream;
+    const int n = ctx->n;
+    for (auto &s : ctx->shards) {
+        // x (initial guess) replicated for the first GEMV, x_sub = x[rows]  (cg.cc:72, 80)
+        HIP_TRY(ctx, hipMemcpyAsync(s.p_full, x0, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+        if (s.rows > 0)
+            HIP_TRY(ctx, hipMemcpyAsync(s.x, s.p_full + s.row0, (size_t)s.rows * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    for (auto &s : ctx->shards) CGX_TRY(run_gemv(ctx, s, nullptr, false));                           // cg.cc:79-81
+    for (auto &s : ctx->shards)
+        HIP_TRY(ctx, cgx::launch_init_residual(s.rows, s.b, s.Ap, s.r, s.p_full + s.row0, s.partials, st));   // cg.cc:82-85
+    for (auto &s : ctx->shards)
+        HIP_TRY(ctx, cgx::launch_reduce_partials(s.partials, cgx::update_xr_grid(s.rows), &s.sc->local[cgx::kSlotRr],
+                                                 nullptr, st));                                      // cg.cc:91
+    CGX_TRY(gather_scalars(ctx));                                                                    // cg.cc:92
+    for (auto &s : ctx->shards) HIP_TRY(ctx, cgx::launch_set_rsold(s.sc, gathered_ptr(ctx, s), ctx->nranks, st));
+    CGX_TRY(gather_p(ctx));                                                                          // cg.cc:87-88
+    ctx->in_solve = true;
+    return CGX_OK;
+}
+
+cgx_status cgx_solve_steps(cgx_ctx *ctx, int nsteps, int *done_out)
+{
+    if (!ctx || !ctx->in_solve) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_solve_steps outside begin/end");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const double t0 = wall_now();
+    const int every = ctx->cfg.check_every;
+    int slot = 0;
+    bool pending[2] = {false, false};
+    bool stop = ctx->done;
+    int left = std::min(nsteps, ctx->max_iter - ctx->k);
+    while (left > 0 && !stop) {
+        const int batch = std::min(left, every);
+        for (int i = 0; i < batch; ++i) CGX_TRY(enqueue_iteration(ctx, ctx->k + i));
+        ctx->k += batch;
+        left -= batch;
+        // publish {done,k_final} after this batch; look at the batch BEFORE it, so one batch stays queued
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags + 2 * slot, &ctx->shards[0].sc->done, 2 * sizeof(int),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->flag_ev[slot], ctx->stream));
+        pending[slot] = true;
+        slot ^= 1;
+        if (pending[slot]) {
+            HIP_TRY(ctx, hipEventSynchronize(ctx->flag_ev[slot]));
+            pending[slot] = false;
+            if (ctx->h_flags[2 * slot]) stop = true;   // identical on every rank: rsnew is bit-identical (cg.cc:117-121)
+        }
+    }
+    CGX_TRY(read_flags_sync(ctx));
+    if (ctx->cfg.profile_gemv) CGX_TRY(harvest_gemv_events(ctx));
+    ctx->t_loop += wall_now() - t0;
+    if (done_out) *done_out = ctx->done ? 1 : 0;
+    return CGX_OK;
+}
+
+cgx_status cgx_solve_end(cgx_ctx *ctx, double *x, cgx_result *res)
+{
+    if (!ctx || !ctx->in_solve) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_solve_end outside begin");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    CGX_TRY(read_flags_sync(ctx));
+    const int k_exit = ctx->done ? ctx->k_final : ctx->k;
+
+    // Gather x (MPI_Gatherv, cg.cc:140-142) into the replicated vector, then the DEBUG verification
+    // (cg.cc:144-151) with the same K1, distributed over the shards instead of rank 0 alone.
+    for (auto &s : ctx->shards)
+        if (s.rows > 0)
+            HIP_TRY(ctx, hipMemcpyAsync(s.p_full + s.row0, s.x, (size_t)s.rows * sizeof(double), hipMemcpyDeviceToDevice, st));
+    CGX_TRY(gather_p(ctx));
+    for (auto &s : ctx->shards) CGX_TRY(run_gemv(ctx, s, nullptr, false));
+    for (auto &s : ctx->shards) HIP_TRY(ctx, cgx::launch_debug_norms(s.rows, s.Ap, s.b, s.x, s.partials, st));
+    for (auto &s : ctx->shards)
+        HIP_TRY(ctx, cgx::launch_reduce_partials3(s.partials, cgx::update_xr_grid(s.rows), s.sc->local, st));
+    CGX_TRY(gather_scalars(ctx));
+
+    Shard &s0 = ctx->shards[0];
+    Scalars hs;
+    std::vector<double> hg((size_t)cgx::kMaxRanks * cgx::kSlots, 0.0);
+    HIP_TRY(ctx, hipMemcpyAsync(&hs, s0.sc, sizeof hs, hipMemcpyDeviceToHost, st));
+    if (ctx->cfg.comm_mode != CGX_COMM_SELF)
+        HIP_TRY(ctx, hipMemcpyAsync(hg.data(), s0.gathered, hg.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (x) HIP_TRY(ctx, hipMemcpyAsync(x, s0.p_full, (size_t)ctx->n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (ctx->cfg.comm_mode == CGX_COMM_SELF)
+        for (int v = 0; v < cgx::kSlots; ++v) hg[v] = hs.local[v];
+    double sums[3] = {0, 0, 0};
+    for (int v = 0; v < 3; ++v)
+        for (int q = 0; q < ctx->nranks; ++q) sums[v] += hg[(size_t)q * cgx::kSlots + v];
+
+    ctx->in_solve = false;
+    if (res) {
+        memset(res, 0, sizeof *res);
+        res->iterations = k_exit;
+        res->converged = ctx->done ? 1 : 0;
+        res->residual_prev = std::sqrt(hs.rs[k_exit & 1]);         // sqrt(rsold) as printed, cg.cc:152-153
+        res->residual_last = std::sqrt(hs.rs[(k_exit + 1) & 1]);
+        if (!ctx->done) res->residual_last = res->residual_prev;    // loop ran out: rsold == rsnew (cg.cc:132)
+        res->x_norm = std::sqrt(sums[2]);
+        res->rel_residual = std::sqrt(sums[0]) / std::sqrt(sums[1]);
+        res->seconds_solve = wall_now() - ctx->t_begin;
+        res->seconds_loop = ctx->t_loop;
+        res->gemv_launches = ctx->gemv_launches;
+        res->gemv_ms_avg = ctx->gemv_launches ? ctx->gemv_ms_sum / (double)ctx->gemv_launches : 0.0;
+        res->gemv_ms_min = ctx->gemv_ms_min;
+        res->gemv_bytes = 8.0 * ((double)s0.rows * ctx->n + ctx->n + s0.rows);
+    }
+    return CGX_OK;
+}
+
+cgx_status cgx_solve(cgx_ctx *ctx, double *x, cgx_result *res)
+{
+    if (!ctx || !x) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_solve: bad argument");
+    CGX_TRY(cgx_solve_begin(ctx, x));
+    int done = 0;
+    CGX_TRY(cgx_solve_steps(ctx, ctx->max_iter, &done));
+    return cgx_solve_end(ctx, x, res);
+}
+
+// ---- kernel probes -------------------------------------------------------------------------------------
+cgx_status cgx_probe_gemv(cgx_ctx *ctx, const double *p, double *y, double *pAp)
+{
+    if (!ctx || !p || !y) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_probe_gemv: bad argument");
+    if (!ctx->have_matrix) return fail(ctx, CGX_ERR_BAD_ARG, "no matrix");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    double total = 0.0;
+    for (auto &s : ctx->shards) {
+        HIP_TRY(ctx, hipMemcpyAsync(s.p_full, p, (size_t)ctx->n * sizeof(double), hipMemcpyHostToDevice, st));
+        CGX_TRY(run_gemv(ctx, s, nullptr, false));
+        HIP_TRY(ctx, cgx::launch_reduce_partials(s.partials, s.plan.grid, &s.sc->local[cgx::kSlotConj], nullptr, st));
+        double part = 0.0;
+        if (s.rows > 0)
+            HIP_TRY(ctx, hipMemcpyAsync(y + s.row0, s.Ap, (size_t)s.rows * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(&part, &s.sc->local[cgx::kSlotConj], sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        total += part;
+    }
+    ctx->ev_used = 0;
+    if (pAp) *pAp = total;
+    return CGX_OK;
+}
+
+cgx_status cgx_probe_vector_ops(cgx_ctx *ctx, int n, double alpha, double beta, double *x, double *r, double *p,
+                                const double *Ap, double *rr)
+{
+    if (!ctx || n <= 0 || !x || !r || !p || !Ap) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_probe_vector_ops: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    double *dx = nullptr, *dr = nullptr, *dp = nullptr, *dAp = nullptr, *dpart = nullptr;
+    Scalars *dsc = nullptr;
+    const size_t bytes = (size_t)n * sizeof(double);
+    const int grid = cgx::update_xr_grid(n);
+    HIP_TRY(ctx, hipMalloc(&dx, bytes));
+    HIP_TRY(ctx, hipMalloc(&dr, bytes));
+    HIP_TRY(ctx, hipMalloc(&dp, bytes));
+    HIP_TRY(ctx, hipMalloc(&dAp, bytes));
+    HIP_TRY(ctx, hipMalloc(&dpart, (size_t)grid * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc(&dsc, sizeof(Scalars)));
+    // Force the wanted alpha and beta through the production kernels: with rsold = alpha and conj = 1,
+    // K3 computes alpha / max(1, alpha*1e-14) = alpha; with rsnew = beta*alpha, K4 computes beta.
+    Scalars hs{};
+    hs.rs[0] = alpha;
+    hs.local[cgx::kSlotConj] = 1.0;
+    hs.local[cgx::kSlotRr] = beta * alpha;
+    HIP_TRY(ctx, hipMemcpyAsync(dsc, &hs, sizeof hs, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dx, x, bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dr, r, bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dp, p, bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dAp, Ap, bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, cgx::launch_update_xr(n, dp, dAp, dx, dr, dsc, 0, dsc->local, 1, dpart, st));
+    double rr_host = 0.0;
+    double *drr = nullptr;
+    HIP_TRY(ctx, hipMalloc(&drr, sizeof(double)));
+    HIP_TRY(ctx, cgx::launch_reduce_partials(dpart, grid, drr, nullptr, st));
+    HIP_TRY(ctx, cgx::launch_update_p(n, dr, dp, dsc, 0, 0, -1.0 /* never converges */, dsc->local, 1, st));
+    HIP_TRY(ctx, hipMemcpyAsync(x, dx, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(r, dr, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(p, dp, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(&rr_host, drr, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (rr) *rr = rr_host;
+    (void)hipFree(dx); (void)hipFree(dr); (void)hipFree(dp); (void)hipFree(dAp); (void)hipFree(dpart);
+    (void)hipFree(dsc); (void)hipFree(drr);
+    return CGX_OK;
+}
+
+cgx_status cgx_probe_get_matrix_rows(cgx_ctx *ctx, int local_shard, double *A_out, int *row0, int *rows)
+{
+    if (!ctx || local_shard < 0 || local_shard >= (int)ctx->shards.size())
+        return fail(ctx, CGX_ERR_BAD_ARG, "cgx_probe_get_matrix_rows: bad shard");
+    if (!ctx->have_matrix) return fail(ctx, CGX_ERR_BAD_ARG, "no matrix");
+    Shard &s = ctx->shards[local_shard];
+    if (row0) *row0 = s.row0;
+    if (rows) *rows = s.rows;
+    if (A_out && s.rows > 0) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipMemcpy2D(A_out, (size_t)ctx->n * sizeof(double), s.A, (size_t)ctx->lda * sizeof(double),
+                                 (size_t)ctx->n * sizeof(double), (size_t)s.rows, hipMemcpyDeviceToHost));
+    }
+    return CGX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,144 @@
+/*
+ * cgx.h -- C ABI of libcgx, the MI355X (gfx950) drop-in for the reference's CGSolver::solve() path.
+ *
+ * The reference (federicobetti99/Conjugate-Gradient) has no plugin/FFI layer: its seam is the C++
+ * class CGSolver (code/MPI/cg.hh:11-57, code/CUDA/cg.hh:13-45) called once from main
+ * (code/MPI/cg_main.cc:28-55).  Each entry point below names the reference member it replaces.
+ * A host-side `class CGSolver` with the reference's method names, built on this ABI, lives in
+ * conjugate-gradient_amd/host/cg.hh; INTEGRATION.md shows the binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain C, no torch / HIP types in any signature; all pointers are HOST pointers;
+ *   - every function returns a cgx_status (0 = ok) and never calls exit();
+ *   - a context is not thread-safe: one caller thread (the reference is MPI_THREAD_SINGLE,
+ *     code/MPI/cg_main.cc:15);
+ *   - all floating point is IEEE fp64, indices are int like the reference (code/MPI/matrix.hh:17)
+ *     but device offsets are 64-bit.
+ *
+ * Sharding (code/MPI/cg.cc:59-75, 236-268): the matrix is row-block partitioned over `nranks`
+ * shards exactly as partition_matrix does.  CGX_COMM_RCCL = one OS process per GPU (the MPI model),
+ * RCCL AllReduce/AllGather over xGMI in place of MPI_Allreduce/MPI_Allgatherv.
+ * CGX_COMM_LOOPBACK = `nranks` logical shards on ONE device in one process (same kernels, same
+ * collective sequencing, in-process exchange) -- the CI stand-in for a multi-GPU node.
+ */
+#ifndef CGX_H
+#define CGX_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CGX_VERSION 1
+#define CGX_UNIQUE_ID_BYTES 128
+
+typedef enum cgx_status {
+    CGX_OK = 0,
+    CGX_ERR_BAD_ARG = 1,      /* null pointer, n <= 0, call out of sequence ...            */
+    CGX_ERR_IO = 2,           /* file could not be opened / parsed (matrix_coo.cc:14-33)    */
+    CGX_ERR_HIP = 3,          /* a HIP runtime call failed                                  */
+    CGX_ERR_RCCL = 4,         /* an RCCL call failed or librccl could not be loaded         */
+    CGX_ERR_OOM = 5,          /* host or device allocation failed                           */
+    CGX_ERR_NO_DEVICE = 6,    /* no gfx950 device visible: the product path has NO CPU fallback */
+    CGX_ERR_UNSUPPORTED = 7   /* e.g. Matrix-Market field/format this reader does not take  */
+} cgx_status;
+
+typedef enum cgx_comm_mode {
+    CGX_COMM_SELF = 0,        /* 1 shard, 1 device, no collectives (psize == 1)             */
+    CGX_COMM_LOOPBACK = 1,    /* nranks logical shards on one device, in-process exchange   */
+    CGX_COMM_RCCL = 2         /* this process is shard `rank` of `nranks`, RCCL over xGMI   */
+} cgx_comm_mode;
+
+typedef struct cgx_config {
+    int  struct_version;      /* = CGX_VERSION                                              */
+    int  comm_mode;           /* cgx_comm_mode                                              */
+    int  device;              /* HIP device ordinal this process drives                     */
+    int  rank;                /* CGX_COMM_RCCL: this process's shard; else 0                */
+    int  nranks;              /* number of row blocks (the reference's psize)               */
+    unsigned char unique_id[CGX_UNIQUE_ID_BYTES]; /* CGX_COMM_RCCL: from cgx_comm_unique_id */
+    int  gemv_variant;        /* 0 = library default; see DESIGN.md "K1 variants"           */
+    int  lda_pad;             /* extra doubles added to the row pitch (-1 = library default)*/
+    int  check_every;         /* iterations between host polls of the device `done` flag (0 = default) */
+    int  profile_gemv;        /* 1 = bracket every K1 launch with HIP events                */
+    int  use_graph;           /* 1 = replay the iteration body from a hipGraph              */
+    int  reserved[8];
+} cgx_config;
+
+typedef struct cgx_result {
+    int    iterations;        /* k at loop exit, code/MPI/cg.cc:95-137 (index of converging iteration, or max_iter) */
+    int    converged;         /* the break at cg.cc:120-121 was taken                       */
+    double residual_prev;     /* sqrt(rsold): the "residual" the DEBUG line prints (cg.cc:152-153) */
+    double residual_last;     /* sqrt(rsnew) of the last executed iteration                 */
+    double x_norm;            /* ||x||             (cg.cc:151)                              */
+    double rel_residual;      /* ||Ax-b|| / ||b||  (cg.cc:145-150)                          */
+    double seconds_solve;     /* reference timing window: all of solve() (cg_main.cc:53-55) */
+    double seconds_loop;      /* the k-loop only                                            */
+    double gemv_ms_avg;       /* mean K1 launch duration (HIP events), 0 if not profiled    */
+    double gemv_ms_min;
+    long long gemv_launches;  /* K1 launches that were event-timed                          */
+    double gemv_bytes;        /* algorithmic bytes of ONE K1 launch on this shard: 8*(rows*n + n + rows) */
+    double reserved[4];
+} cgx_result;
+
+typedef struct cgx_ctx cgx_ctx;
+
+/* ---- life cycle -------------------------------------------------------------------------- */
+void        cgx_config_init(cgx_config *cfg);                 /* fills defaults (SELF, device 0, 1 rank) */
+cgx_status  cgx_comm_unique_id(unsigned char out[CGX_UNIQUE_ID_BYTES]);  /* ncclGetUniqueId; rank 0 calls it, the launcher broadcasts it (replaces MPI_Init, cg_main.cc:15-20) */
+cgx_status  cgx_create(cgx_ctx **out, const cgx_config *cfg);
+cgx_status  cgx_destroy(cgx_ctx *ctx);
+const char *cgx_last_error(const cgx_ctx *ctx);               /* ctx may be NULL: error of the last failed cgx_create on this thread */
+const char *cgx_status_string(cgx_status s);
+
+/* ---- CGSolver::partition_matrix, code/MPI/cg.cc:236-268 (pure host function) ------------- */
+cgx_status  cgx_partition(int n, int psize, int *start_rows, int *num_rows);
+
+/* ---- problem definition ------------------------------------------------------------------ */
+/* CGSolver::generate_lap2d_matrix(size), cg.cc:159-188: builds this shard's row block ON DEVICE,
+ * sets m = n = max_iter = size (cg.cc:170-172). */
+cgx_status  cgx_generate_lap2d_matrix(cgx_ctx *ctx, int size);
+/* CGSolver::read_matrix + Matrix::read (cg.cu:307-321, matrix.cc:6-22): caller hands the dense
+ * row-major n x n matrix (host, leading dimension lda doubles); the library copies this shard's
+ * rows to the device.  Sets m = n, max_iter = n (code/CUDA/cg.cu:236 loops to m_n). */
+cgx_status  cgx_set_matrix_dense(cgx_ctx *ctx, const double *A, long lda, int n);
+/* MatrixCOO::read + Matrix::read (matrix_coo.cc:7-60, matrix.cc:6-22) done by the library:
+ * Matrix-Market `matrix coordinate {real,integer,double} {general,symmetric}` -> device row block,
+ * without a dense n*n host staging copy. */
+cgx_status  cgx_read_matrix(cgx_ctx *ctx, const char *mtx_path);
+/* CGSolver::init_source_term(h), cg.cc:218-234: b evaluated on the HOST with libm sin so it is
+ * bit-identical to the reference's, then this shard's slice is uploaded. */
+cgx_status  cgx_init_source_term(cgx_ctx *ctx, double h);
+cgx_status  cgx_set_source_term(cgx_ctx *ctx, const double *b /* n doubles */);
+/* CGSolver::set_max_iter (cg.cc:204-216) and CGSolver::tolerance (cg.hh:39) */
+cgx_status  cgx_set_max_iter(cgx_ctx *ctx, int max_iter);
+cgx_status  cgx_set_tolerance(cgx_ctx *ctx, double tol);
+cgx_status  cgx_get_size(const cgx_ctx *ctx, int *m, int *n);   /* CGSolver::m(), n() */
+
+/* ---- CGSolver::solve, cg.cc:38-156 ------------------------------------------------------- */
+/* x: n doubles, in = initial guess (cg_main.cc:49-50 passes zeros), out = solution (every rank
+ * gets the full x; the reference fills rank 0 only, cg.cc:140-142).  res may be NULL. */
+cgx_status  cgx_solve(cgx_ctx *ctx, double *x, cgx_result *res);
+
+/* The same path cut at its seams, for bench.py's warmup / timed-steps contract:
+ *   begin  = cg.cc:49-92 (setup, initial residual GEMV, p0 gather, rsold)
+ *   steps  = `nsteps` bodies of the loop cg.cc:96-137 (stops early on convergence); synchronises
+ *   end    = cg.cc:140-154 (gather x, DEBUG verification) and fills res. */
+cgx_status  cgx_solve_begin(cgx_ctx *ctx, const double *x0);
+cgx_status  cgx_solve_steps(cgx_ctx *ctx, int nsteps, int *done_out);
+cgx_status  cgx_solve_end(cgx_ctx *ctx, double *x, cgx_result *res);
+
+/* ---- kernel probes (parity tests of the individual hot ops through the C ABI) ------------- */
+/* Ap = A_shard * p  (K1; cblas_dgemv at cg.cc:101-102) for every local shard; y receives the n
+ * results in global row order (LOOPBACK/SELF) or this rank's rows at their global offset (RCCL);
+ * *pAp receives sum_i p_i * Ap_i over the local rows (the fused cblas_ddot of cg.cc:105). */
+cgx_status  cgx_probe_gemv(cgx_ctx *ctx, const double *p, double *y, double *pAp);
+/* One pass of K3 (cg.cc:110-117) then K4 (cg.cc:124-129) on caller data of length n, single shard:
+ * x += alpha p; r -= alpha Ap; *rr = r.r; p = r + beta p. */
+cgx_status  cgx_probe_vector_ops(cgx_ctx *ctx, int n, double alpha, double beta, double *x, double *r,
+                                 double *p, const double *Ap, double *rr);
+/* Copy this shard's device row block (rows x n, dense, row-major) back to the host. */
+cgx_status  cgx_probe_get_matrix_rows(cgx_ctx *ctx, int local_shard, double *A_out, int *row0, int *rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CGX_H */
