@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- CG iterations/s and K1 HBM-roofline fraction on MI355X (BASELINE.json metric).
+
+    python bench.py                       # 1 GPU, generate_lap2d N=32768, 500 timed iterations (configs[2])
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W          # row-block over N GPUs (configs[3], strong scaling)
+
+A "step" is one body of the CG loop (code/MPI/cg.cc:96-137 of the reference): one A.p GEMV over this
+rank's row block, two dot products, the x/r/p updates and the three exchanges.  Inputs are synthetic and
+HBM-resident before the timed region: A = generate_lap2d_matrix(N) built on the device, b = init_source_term(1/N).
+W warmup steps, then exactly K steps between barrier + torch.cuda.synchronize(); MAX over ranks; rank 0
+prints ONE JSON line.  value = K / t for the whole job (every rank advances the same K iterations).
+
+Extra objects in the line:
+  roofline     -- K1 (the GEMV) against the 8 TB/s HBM peak: algorithmic bytes 8*(rows*N + N + rows) per launch
+                  divided by the mean launch duration measured with HIP events on the library's own stream.
+  cpu_baseline -- the CPU oracle (oracle/cg_oracle.c, a port of the reference's serial path) run for a few
+                  iterations of the same workload on one host core (rank 0, 1-GPU runs only).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=500)      # BASELINE.json configs[2]: fixed 500 iterations
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n", type=int, default=0, help="matrix size (default 32768; weak mode: floor(16384*sqrt(P)))")
+    ap.add_argument("--mode", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--variant", type=int, default=0, help="K1 shape override (DESIGN.md)")
+    ap.add_argument("--lda-pad", type=int, default=-1)
+    ap.add_argument("--cpu-baseline-iters", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile-gemv", action="store_true", help="do not bracket K1 with HIP events")
+    return ap.parse_args()
+
+
+def pmc_traffic(n, nranks):
+    """HBM bytes per K1 launch from a committed rocprofv3 --pmc pass (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "k1_hbm_traffic.json")
+    try:
+        rows = json.load(open(path))["rows"]
+    except Exception:
+        return None
+    for r in rows:
+        if r.get("n") == n and r.get("nranks") == nranks:
+            return r.get("hbm_bytes_per_launch")
+    return None
+
+
+def broadcast_bytes(dist, payload, nbytes, device):
+    """Rank 0's `payload` (bytes of length nbytes) to every rank of the default process group."""
+    import torch
+    if dist.get_rank() == 0:
+        assert len(payload) == nbytes
+        t = torch.tensor(list(payload), dtype=torch.uint8, device=device)
+    else:
+        t = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    dist.broadcast(t, src=0)
+    return bytes(t.cpu().tolist())
+
+
+def cpu_baseline(n, iters):
+    import __graft_entry__ as g
+    O = g.load_oracle()
+    t0 = time.time()
+    _, r = O.solve_lap2d(n, iters, 0.0, 1)     # tol 0: never converges, exactly `iters` loop bodies
+    wall = time.time() - t0
+    return {
+        "value": iters / r["seconds_loop"], "unit": "iterations/s", "cores": 1, "kind": "port",
+        "sample": "oracle/cg_oracle.c serial CG, generate_lap2d N=%d, %d of the loop bodies timed (loop only, "
+                  "%.1f s; %.1f s incl. building the 8*N^2-byte matrix)" % (n, iters, r["seconds_loop"], wall),
+        "gemv_GBs": 8.0 * n * n * iters / r["seconds_loop"] / 1e9,
+    }
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                     % (args.gpus, args.gpus))
+        args.gpus = world
+
+    import numpy as np
+    import torch   # before libcgx: the library then shares the HIP/RCCL instances torch loaded
+    import __graft_entry__ as g
+
+    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path to time"
+    torch.cuda.set_device(local_rank)
+    pkg = g.load_package()
+
+    dist = None
+    uid = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+        # replaces mpirun's wire-up (MPI_Init, cg_main.cc:15-20): every rank gets rank 0's RCCL id
+        uid = broadcast_bytes(dist, pkg.comm_unique_id() if rank == 0 else None, pkg.cgx.UNIQUE_ID_BYTES, "cuda")
+
+    if args.n:
+        n = args.n
+    elif args.mode == "weak":
+        n = int(math.floor(16384 * math.sqrt(world)))   # code/MPI/cg.run:22-44 rounding rule, N^2/P constant
+    else:
+        n = 32768
+
+    solver = pkg.CGSolver(comm_mode=pkg.COMM_RCCL if world > 1 else pkg.COMM_SELF, nranks=world, rank=rank,
+                          device=local_rank, unique_id=uid, gemv_variant=args.variant, lda_pad=args.lda_pad,
+                          profile_gemv=not args.no_profile_gemv)
+    solver.generate_lap2d_matrix(n)
+    solver.set_max_iter(args.warmup + args.steps)
+    solver.tolerance(0.0)                  # fixed-iteration run: the break of cg.cc:120 is never taken
+    solver.init_source_term(1.0 / n)
+    x = np.zeros(n)
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    solver.solve_begin(x)
+    solver.solve_steps(args.warmup)
+    sync()
+    t0 = time.perf_counter()
+    solver.solve_steps(args.steps)         # enqueues K loop bodies and synchronises the library's stream
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    res = solver.solve_end(x)
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        g_ms = torch.tensor([res["gemv_ms_avg"]], dtype=torch.float64, device="cuda")
+        dist.all_reduce(g_ms, op=dist.ReduceOp.MAX)
+        gemv_ms = float(g_ms.item())
+    else:
+        gemv_ms = res["gemv_ms_avg"]
+
+    if rank == 0:
+        rows0 = pkg.partition(n, world)[1][0]
+        gemv_bytes = 8.0 * (rows0 * n + n + rows0)            # A rows once + p + Ap
+        ach = gemv_bytes / (gemv_ms * 1e-3) / 1e9 if gemv_ms > 0 else None
+        line = {
+            "metric": "cg_iterations_per_sec",
+            "value": args.steps / elapsed,
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": args.mode,
+            "vs_baseline": None,           # the reference publishes seconds only, nothing at this N
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "generate_lap2d_matrix N=%d, init_source_term(1/N), fixed-iteration dense fp64 CG "
+                            "(BASELINE.json configs[%d])" % (n, 2 if world == 1 else (3 if args.mode == "strong" else 4)),
+                "n": n, "rows_per_gpu": rows0, "parallelism": "rowblock%d" % world,
+                "collectives": "none" if world == 1 else "RCCL allgather(scalars) x2 + allgather(p) per iteration",
+                "k1_variant": args.variant,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": (ach / HBM_PEAK_GBS) if ach else None,
+                "traffic": pmc_traffic(n, world),
+                "kernel": "k_gemv (K1, A.p of this rank's row block)", "bytes_per_launch": gemv_bytes,
+                "avg_launch_ms": gemv_ms, "launches_timed": res["gemv_launches"],
+            },
+            "aggregate_gemv_GBs": (ach * world) if ach else None,
+            "whole_iteration_GBs_per_gpu": 8.0 * (rows0 * n + n + 14 * rows0) / (elapsed / args.steps) / 1e9,
+            "residual_after_run": res["residual_prev"],
+            "iterations_done": res["iterations"],
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(n, args.cpu_baseline_iters)
+        print(json.dumps(line), flush=True)
+
+    solver.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

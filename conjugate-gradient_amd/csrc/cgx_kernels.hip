@@ -449,9 +449,9 @@ GemvPlan plan_gemv(int variant, int rows, int ncols)
         else if (rows >= 2048) { pl.R = 4; pl.U = 4; }
         else { pl.R = 2; pl.U = 4; }
     } else {
-        // explicit shape: variant*1000 + R*100 + U*10 + nt   (e.g. 1821, 2441)
-        pl.variant = variant / 1000;
-        pl.R = (variant / 100) % 10;
+        // explicit shape: variant*10000 + R*100 + U*10 + nt   (e.g. 10821, 20441, 11611)
+        pl.variant = variant / 10000;
+        pl.R = (variant / 100) % 100;
         pl.U = (variant / 10) % 10;
         pl.nt = variant % 10;
     }

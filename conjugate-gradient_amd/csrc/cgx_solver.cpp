@@ -760,6 +760,10 @@ cgx_status cgx_solve_steps(cgx_ctx *ctx, int nsteps, int *done_out)
     if (!ctx || !ctx->in_solve) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_solve_steps outside begin/end");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const double t0 = wall_now();
+    // K1 statistics describe the most recent steps call (bench.py: the timed region, not the warmup)
+    ctx->ev_used = 0;
+    ctx->gemv_ms_sum = ctx->gemv_ms_min = 0;
+    ctx->gemv_launches = 0;
     const int every = ctx->cfg.check_every;
     int slot = 0;
     bool pending[2] = {false, false};

@@ -1,0 +1,97 @@
+"""CPU-side tests of the drop-in boundary: libcgx.so loads, exports every symbol include/cgx.h declares,
+its host-only entry points work, and everything that needs the GPU fails LOUDLY without one (no fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _has_gpu():
+    import torch
+    return torch.cuda.is_available()
+
+
+def declared_symbols():
+    hdr = open(os.path.join(ROOT, "include", "cgx.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(cgx_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_header_and_binding_agree(pkg):
+    assert declared_symbols() == sorted(pkg.cgx.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    L = pkg.cgx.lib()
+    for name in declared_symbols():
+        assert hasattr(L, name), name
+    out = subprocess.run(["nm", "-D", "--defined-only", pkg.cgx.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (cgx_\w+)", out))
+    assert set(declared_symbols()) <= exported
+
+
+def test_library_contains_gfx950_code_object(pkg):
+    blob = open(pkg.cgx.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob and b"k_gemv_colsplit" in blob
+
+
+def test_struct_layouts_match_header(pkg):
+    assert C.sizeof(pkg.cgx.Config) == 4 * 5 + 128 + 4 * 5 + 4 * 8
+    assert C.sizeof(pkg.cgx.Result) == 8 + 8 * 8 + 8 + 8 + 8 * 4
+
+
+def test_partition_through_abi_matches_oracle(pkg, oracle):
+    for n, p in [(10, 1), (10, 3), (1000, 3), (32768, 8), (46340, 8), (23170, 2), (5, 8)]:
+        assert pkg.partition(n, p) == oracle.partition(n, p)
+
+
+def test_status_strings(pkg):
+    L = pkg.cgx.lib()
+    assert L.cgx_status_string(0) == b"ok"
+    assert b"no CPU fallback" in L.cgx_status_string(6)
+
+
+def test_bad_arguments_are_rejected_not_crashed(pkg):
+    L = pkg.cgx.lib()
+    assert L.cgx_partition(10, 0, None, None) == 1
+    assert L.cgx_set_max_iter(None, 3) == 1
+    assert L.cgx_solve(None, None, None) == 1
+    assert L.cgx_read_matrix(None, b"/nonexistent.mtx") == 1
+
+
+def test_no_gpu_means_loud_failure(pkg):
+    if _has_gpu():
+        pytest.skip("this machine has a GPU")
+    with pytest.raises(pkg.CgxError) as e:
+        pkg.CGSolver()
+    assert e.value.status == 6 and "no CPU fallback" in str(e.value)
+
+
+def test_cli_usage_and_failure_exit_codes(pkg):
+    exe = os.path.join(ROOT, "conjugate-gradient_amd", "cgsolver")
+    assert os.path.exists(exe), "cgsolver not built (run __graft_entry__.build())"
+    r = subprocess.run([exe], capture_output=True, text=True)
+    assert r.returncode == 1 and "Usage" in r.stderr          # code/MPI/cg_main.cc:22-26
+    if not _has_gpu():
+        r = subprocess.run([exe, "64", "/tmp/cgx_never_written.txt"], capture_output=True, text=True)
+        assert r.returncode == 1 and "no CPU fallback" in r.stderr
+        assert not os.path.exists("/tmp/cgx_never_written.txt")
+
+
+def test_product_package_never_touches_the_oracle():
+    """The oracle is test infrastructure: nothing under conjugate-gradient_amd/ or include/ may reference it."""
+    bad = []
+    for base in ("conjugate-gradient_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            if "build" in dp.split(os.sep):
+                continue
+            for f in files:
+                if f.endswith((".py", ".cc", ".cpp", ".hip", ".h", ".hh", "Makefile")):
+                    txt = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"cg_oracle|oracle\.py|from oracle|import oracle|libcg_oracle|load_oracle", txt):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad

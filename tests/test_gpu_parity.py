@@ -1,0 +1,328 @@
+"""Parity tests proper: the HIP path through the C ABI against the CPU oracle, the committed reference
+outputs, and size-independent properties at the BASELINE.json sizes.  All marked gpu.
+
+Tolerances (fp64; north_star's "residual within 1e-10 of reference" read as in SURVEY.md section 4):
+  kernels     : |y - y_oracle| <= 2e-14 * max|y|  (summation-order noise, N <= 8192)
+  fixed-iter  : residual rel. 1e-6, ||dx||/||x|| <= 1e-12, sampled x rel. 1e-12
+  converged   : sqrt(rsnew) < 1e-10 at exit, ||Ax-b||/||b|| <= 1e-11, k within 15 % of the reference's
+"""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def rel(a, b):
+    return abs(a - b) / abs(b)
+
+
+def make(pkg, n=None, mode=None, nranks=1, variant=0, max_iter=None, mtx=None, tol=None, **kw):
+    s = pkg.CGSolver(comm_mode=pkg.COMM_SELF if mode is None else mode, nranks=nranks, gemv_variant=variant, **kw)
+    if mtx:
+        s.read_matrix(mtx)
+    else:
+        s.generate_lap2d_matrix(n)
+    if max_iter is not None:
+        s.set_max_iter(max_iter)
+    if tol is not None:
+        s.tolerance(tol)
+    s.init_source_term(1.0 / s.n())
+    return s
+
+
+# ---- the native library is what runs ------------------------------------------------------------------
+def test_native_library_is_loaded(gpu_pkg):
+    gpu_pkg.CGSolver().close()
+    maps = open("/proc/self/maps").read()
+    assert "libcgx.so" in maps
+
+
+# ---- generator: bit-exact (integer predicate per element) -------------------------------------------------
+@pytest.mark.parametrize("n,mode,p", [(1, None, 1), (2, None, 1), (17, None, 1), (1000, None, 1), (1001, 1, 3), (4096, 1, 8)])
+def test_generator_bit_exact(gpu_pkg, oracle, n, mode, p):
+    with gpu_pkg.CGSolver(comm_mode=gpu_pkg.COMM_SELF if mode is None else gpu_pkg.COMM_LOOPBACK, nranks=p) as s:
+        s.generate_lap2d_matrix(n)
+        blocks = [s.probe_matrix_rows(i) for i in range(p)]
+    starts, counts = oracle.partition(n, p)
+    assert [b[1] for b in blocks] == starts and [b[0].shape[0] for b in blocks] == counts
+    assert np.array_equal(np.vstack([b[0] for b in blocks]), oracle.generate_lap2d(n))
+
+
+# ---- K1 ------------------------------------------------------------------------------------------------
+VARIANTS = [0, 10821, 10820, 10811, 10441, 10421, 10241, 10281, 10181, 11611, 20821, 20811, 20441, 20421, 20241, 20281, 20181]
+
+
+@pytest.mark.parametrize("variant", VARIANTS)
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 129, 512, 1000, 1001, 2049])
+def test_gemv_generated(gpu_pkg, oracle, n, variant):
+    rng = np.random.default_rng(n)
+    with gpu_pkg.CGSolver(gemv_variant=variant) as s:
+        s.generate_lap2d_matrix(n)
+        p = rng.standard_normal(n)
+        y, pap = s.probe_gemv(p)
+    yo = oracle.gemv(oracle.generate_lap2d(n), p)
+    assert np.max(np.abs(y - yo)) <= 2e-14 * max(np.max(np.abs(yo)), 1e-300)
+    assert abs(pap - oracle.dot(p, yo)) <= 1e-12 * np.sum(np.abs(p * yo))
+
+
+@pytest.mark.parametrize("variant", [0, 10821, 10441, 20821, 20441])
+@pytest.mark.parametrize("n", [5, 300, 1000, 2047])
+def test_gemv_dense_random(gpu_pkg, oracle, n, variant):
+    """Fully dense random A (every element matters, unlike the 5-band generator) incl. odd n."""
+    rng = np.random.default_rng(7 * n + variant)
+    A = rng.standard_normal((n, n))
+    p = rng.standard_normal(n)
+    with gpu_pkg.CGSolver(gemv_variant=variant) as s:
+        s.set_matrix_dense(A)
+        y, pap = s.probe_gemv(p)
+        back, _ = s.probe_matrix_rows(0)
+    assert np.array_equal(back, A)
+    yo = oracle.gemv(A, p)
+    scale = np.abs(A) @ np.abs(p)
+    assert np.all(np.abs(y - yo) <= 4e-16 * np.sqrt(n) * scale + 1e-300)
+    assert abs(pap - oracle.dot(p, yo)) <= 1e-13 * np.sum(np.abs(p * yo))
+
+
+@pytest.mark.parametrize("n,p", [(1000, 3), (1000, 7), (2048, 2), (2048, 8), (5, 8), (1025, 16)])
+def test_gemv_row_blocks_loopback(gpu_pkg, oracle, n, p):
+    rng = np.random.default_rng(n + p)
+    A = rng.standard_normal((n, n))
+    v = rng.standard_normal(n)
+    with gpu_pkg.CGSolver(comm_mode=gpu_pkg.COMM_LOOPBACK, nranks=p) as s:
+        s.set_matrix_dense(A)
+        y, pap = s.probe_gemv(v)
+    yo = oracle.gemv(A, v)
+    assert np.max(np.abs(y - yo)) <= 1e-13 * np.max(np.abs(yo))
+    assert abs(pap - oracle.dot(v, yo)) <= 1e-12 * np.sum(np.abs(v * yo))
+
+
+def test_gemv_is_deterministic(gpu_pkg):
+    rng = np.random.default_rng(3)
+    with gpu_pkg.CGSolver() as s:
+        s.generate_lap2d_matrix(4096)
+        p = rng.standard_normal(4096)
+        y1, d1 = s.probe_gemv(p)
+        y2, d2 = s.probe_gemv(p)
+    assert np.array_equal(y1, y2) and d1 == d2      # no atomics anywhere: bitwise reproducible
+
+
+def test_gemv_linearity(gpu_pkg):
+    """Size-independent property at a BASELINE size: A(ap+bq) = a Ap + b Aq (N=16384, 2 GiB matrix)."""
+    n = 16384
+    rng = np.random.default_rng(11)
+    p, q = rng.standard_normal(n), rng.standard_normal(n)
+    with gpu_pkg.CGSolver() as s:
+        s.generate_lap2d_matrix(n)
+        yp, _ = s.probe_gemv(p)
+        yq, _ = s.probe_gemv(q)
+        yc, _ = s.probe_gemv(2.0 * p - 0.5 * q)
+        ones, _ = s.probe_gemv(np.ones(n))
+    assert np.max(np.abs(yc - (2.0 * yp - 0.5 * yq))) <= 1e-13 * np.max(np.abs(yc))
+    inc = int(np.floor(np.sqrt(n)))
+    assert ones[n // 2] == 0.0 and ones[0] == 2.0 and ones[inc + 1] == 0.0     # row sums of the penta-diagonal matrix
+
+
+# ---- K3 / K4 -----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 255, 256, 257, 1000, 4096, 32768, 100003])
+def test_vector_ops(gpu_pkg, oracle, n):
+    rng = np.random.default_rng(n)
+    x, r, p, Ap = (rng.standard_normal(n) for _ in range(4))
+    alpha, beta = 0.37, 1.9
+    with gpu_pkg.CGSolver() as s:
+        x2, r2, p2, rr = s.probe_vector_ops(alpha, beta, x, r, p, Ap)
+    xe = x + alpha * p                    # cblas_daxpy, cg.cc:110
+    re_ = r - alpha * Ap                  # cg.cc:113
+    pe = re_ + beta * p                   # cg.cc:127-129
+    assert np.allclose(x2, xe, rtol=0, atol=4e-16 * (np.abs(x) + np.abs(alpha * p)).max())
+    assert np.allclose(r2, re_, rtol=0, atol=4e-16 * (np.abs(r) + np.abs(alpha * Ap)).max())
+    assert np.allclose(p2, pe, rtol=0, atol=8e-16 * (np.abs(re_) + np.abs(beta * p)).max())
+    assert rel(rr, oracle.dot(re_, re_)) < 1e-13
+
+
+# ---- whole solve vs oracle -----------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,max_iter,mode,p,variant", [
+    (64, 10, None, 1, 0), (1000, 100, None, 1, 0), (1024, 100, None, 1, 20441), (2048, 200, None, 1, 0),
+    (2048, 200, 1, 2, 0), (2048, 200, 1, 4, 0), (2048, 200, 1, 8, 10821), (1000, 150, 1, 3, 0), (1000, 150, 1, 7, 20441),
+    (4096, 50, None, 1, 0), (4096, 200, 1, 8, 0),
+])
+def test_fixed_iteration_solve_matches_oracle(gpu_pkg, oracle, n, max_iter, mode, p, variant):
+    with make(gpu_pkg, n, mode, p, variant, max_iter) as s:
+        x = np.zeros(n)
+        r = s.solve(x)
+    xo, ro = oracle.solve_lap2d(n, max_iter, 1e-10, p)
+    assert r["iterations"] == ro["iterations"] == max_iter and not r["converged"]
+    assert rel(r["residual_prev"], ro["residual_prev"]) < 1e-6
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) < 1e-12
+    assert rel(r["x_norm"], ro["x_norm"]) < 1e-12
+    tol = 1e-5 if ro["rel_residual"] > 1e-9 else 1e-2
+    assert rel(r["rel_residual"], ro["rel_residual"]) < tol
+
+
+@pytest.mark.parametrize("n,mode,p", [(1024, None, 1), (1024, 1, 4), (1000, 1, 3), (2048, None, 1), (4096, None, 1)])
+def test_converged_solve(gpu_pkg, oracle, reference_probe, n, mode, p):
+    with make(gpu_pkg, n, mode, p) as s:
+        x = np.zeros(n)
+        r = s.solve(x)
+    xo, ro = oracle.solve_lap2d(n, None, 1e-10, p)
+    ref = [q for q in reference_probe["generated"] if q["n"] == n and q["max_iter"] is None]
+    assert r["converged"] and r["residual_last"] < 1e-10 <= r["residual_prev"]
+    assert r["rel_residual"] <= 1e-11
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) < 1e-12
+    assert abs(r["iterations"] - ro["iterations"]) <= 0.15 * ro["iterations"]
+    for q in ref:
+        assert abs(r["iterations"] - q["k"]) <= 0.15 * q["k"]
+        assert rel(r["x_norm"], q["x_norm"]) < 1e-6
+
+
+def test_break_semantics_and_no_further_updates(gpu_pkg):
+    """After convergence the remaining enqueued iterations must be no-ops: x from a solve that converged
+    early inside a batch equals x from check_every=1 (host looks after every iteration)."""
+    n = 1024
+    xs, rs = [], []
+    for every in (1, 16, 64):
+        with make(gpu_pkg, n, check_every=every) as s:
+            x = np.zeros(n)
+            rs.append(s.solve(x))
+            xs.append(x)
+    assert rs[0]["iterations"] == rs[1]["iterations"] == rs[2]["iterations"]
+    assert np.array_equal(xs[0], xs[1]) and np.array_equal(xs[0], xs[2])
+    assert rs[0]["residual_prev"] == rs[2]["residual_prev"] and rs[0]["residual_last"] == rs[2]["residual_last"]
+
+
+def test_initial_guess_is_used(gpu_pkg, oracle):
+    n = 512
+    A = oracle.generate_lap2d(n)
+    b = oracle.init_source_term(n)
+    x0 = np.linspace(-1, 1, n)
+    with make(gpu_pkg, n, max_iter=40) as s:
+        x = x0.copy()
+        r = s.solve(x)
+    xo, ro = oracle.solve(A, b, x0, 40, 1e-10, 1)
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) < 1e-12 and rel(r["residual_prev"], ro["residual_prev"]) < 1e-6
+
+
+def test_max_iter_zero_and_exact_solution(gpu_pkg):
+    n = 256
+    with make(gpu_pkg, n, max_iter=0) as s:
+        x = np.zeros(n)
+        r = s.solve(x)
+    assert r["iterations"] == 0 and not r["converged"] and np.all(x == 0) and rel(r["rel_residual"], 1.0) < 1e-15
+    # identity matrix: converges inside iteration 0, so the printed k is 0 (break before ++k, cg.cc:96,120)
+    with gpu_pkg.CGSolver() as s:
+        s.set_matrix_dense(np.eye(n))
+        b = np.arange(1.0, n + 1)
+        s.set_source_term(b)
+        x = np.zeros(n)
+        r = s.solve(x)
+    assert r["converged"] and r["iterations"] == 0 and np.allclose(x, b, rtol=1e-15)
+
+
+# ---- Matrix-Market input surface ------------------------------------------------------------------------------
+def test_mtx_reader_matches_oracle_dense(gpu_pkg, oracle, mtx_path):
+    A, nz, sym = oracle.read_mtx_dense(mtx_path)
+    for mode, p in ((gpu_pkg.COMM_SELF, 1), (gpu_pkg.COMM_LOOPBACK, 3)):
+        with gpu_pkg.CGSolver(comm_mode=mode, nranks=p) as s:
+            s.read_matrix(mtx_path)
+            assert s.n() == 10000 and s.m() == 10000
+            blocks = [s.probe_matrix_rows(i)[0] for i in range(p)]
+        assert np.array_equal(np.vstack(blocks), A)
+
+
+def test_mtx_general_duplicates_and_errors(gpu_pkg, tmp_path):
+    f = tmp_path / "g.mtx"
+    f.write_text("%%MatrixMarket MATRIX Coordinate Real General\n% c\n%c2\n3 3 5\n1 1 2.5\n2 2 1\n3 3 4e0\n1 3 -1\n1 3 -7\n")
+    with gpu_pkg.CGSolver() as s:
+        s.read_matrix(str(f))
+        A, _ = s.probe_matrix_rows(0)
+    assert np.array_equal(A, np.array([[2.5, 0, -7.0], [0, 1, 0], [0, 0, 4.0]]))   # last duplicate wins, not mirrored
+    with gpu_pkg.CGSolver() as s:
+        with pytest.raises(gpu_pkg.CgxError) as e:
+            s.read_matrix(str(tmp_path / "missing.mtx"))
+        assert e.value.status == 2
+        bad = tmp_path / "bad.mtx"
+        bad.write_text("%%MatrixMarket matrix array real general\n2 2\n1\n2\n3\n4\n")
+        with pytest.raises(gpu_pkg.CgxError) as e:
+            s.read_matrix(str(bad))
+        assert e.value.status == 7
+        bad.write_text("not a banner\n")
+        with pytest.raises(gpu_pkg.CgxError):
+            s.read_matrix(str(bad))
+
+
+def test_mtx_solve_matches_reference_golden(gpu_pkg, mtx_path, reference_probe):
+    """BASELINE.json configs[0] input on the GPU path, against the reference's recorded converged run."""
+    row = reference_probe["mtx_lap2D_5pt_n100"][0]
+    with make(gpu_pkg, mtx=mtx_path) as s:
+        x = np.zeros(10000)
+        r = s.solve(x)
+    assert r["converged"] and r["residual_last"] < 1e-10
+    assert abs(r["iterations"] - row["k"]) <= 0.15 * row["k"]
+    assert rel(r["x_norm"], row["x_norm"]) < 1e-6 and r["rel_residual"] <= 1e-11
+    for i, v in row["x_samples"].items():
+        assert rel(x[int(i)], v) < 1e-10, i
+
+
+# ---- BASELINE.json sizes against the reference's own outputs -----------------------------------------------------
+def _check_against_reference(x, r, row):
+    assert r["iterations"] == row["k"]
+    assert rel(r["residual_prev"], row["residual"]) < 1e-6
+    assert rel(r["x_norm"], row["x_norm"]) < 1e-12
+    assert rel(r["rel_residual"], row["rel_residual"]) < 1e-5
+    for i, v in row["x_samples"].items():
+        assert rel(x[int(i)], v) < 1e-12, i
+
+
+def test_config2_n10000_converges_like_reference(gpu_pkg, reference_probe):
+    row = [q for q in reference_probe["generated"] if q["n"] == 10000][0]
+    with make(gpu_pkg, 10000) as s:
+        x = np.zeros(10000)
+        r = s.solve(x)
+    assert r["converged"] and r["residual_last"] < 1e-10
+    assert abs(r["iterations"] - row["k"]) <= 0.10 * row["k"]          # k ~ 607 +- 10 %
+    assert rel(r["x_norm"], row["x_norm"]) < 1e-6 and r["rel_residual"] <= 3e-11
+
+
+@pytest.mark.parametrize("mode,p", [(None, 1), (1, 8)])
+def test_config3_n32768_500_iterations(gpu_pkg, reference_probe, mode, p):
+    """The roofline point and (as 8 logical row blocks on one GPU) the strong-scaling partition."""
+    row = [q for q in reference_probe["generated_large"] if q["n"] == 32768][0]
+    n = 32768
+    with make(gpu_pkg, n, mode, p, max_iter=500) as s:
+        x = np.zeros(n)
+        r = s.solve(x)
+    _check_against_reference(x, r, row)
+
+
+@pytest.mark.parametrize("n,p", [(16384, 1), (23170, 2), (46340, 8)])
+def test_config5_weak_scaling_sizes(gpu_pkg, reference_probe, n, p):
+    """Weak-scaling series, 200 iterations, with the reference's partition incl. the uneven N=46340, P=8
+    (7 x 5792 + 5796 rows) as logical row blocks on one GPU (17.2 GB of A)."""
+    row = [q for q in reference_probe["generated_large"] if q["n"] == n][0]
+    with make(gpu_pkg, n, gpu_pkg.COMM_LOOPBACK if p > 1 else None, p, max_iter=200) as s:
+        x = np.zeros(n)
+        r = s.solve(x)
+    _check_against_reference(x, r, row)
+
+
+# ---- command line -------------------------------------------------------------------------------------------------
+def test_cgsolver_cli_both_forms(gpu_pkg, mtx_path, tmp_path):
+    exe = os.path.join(ROOT, "conjugate-gradient_amd", "cgsolver")
+    out = tmp_path / "strong.txt"
+    r = subprocess.run([exe, "1024", str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.startswith("\t[STEP 17") and "residual = " in r.stdout and "||Ax - b||/||b|| = " in r.stdout
+    n, ps, secs = out.read_text().strip().split(",")
+    assert (n, ps) == ("1024", "1") and float(secs) > 0
+    r = subprocess.run([exe, "2048", str(out), "200", "--loopback", "4"], capture_output=True, text=True)
+    assert r.returncode == 0 and "[STEP 200] residual = 1.331819e-05, ||x|| = 8.808702e+07" in r.stdout
+    assert out.read_text().strip().split("\n")[1].startswith("2048,4,")
+    out2 = tmp_path / "cuda.txt"
+    r = subprocess.run([exe, mtx_path, "1024", "16", "true", str(out2)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "Time for CG (dense solver)  = " in r.stdout and "||x|| = 2.147364e+09" in r.stdout
+    nt, bw, secs = out2.read_text().strip().split(",")
+    assert (nt, bw) == ("1024", "16") and float(secs) > 0

@@ -1,0 +1,175 @@
+"""CPU tests of the parity oracle (oracle/cg_oracle.c) against the reference outputs recorded by the
+survey (tests/golden/reference_probe.json) and against structural truths of the reference's code.
+These pin the oracle; the GPU tests then compare libcgx with the oracle."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+REF = "/root/reference/code/MPI"
+
+
+def rel(a, b):
+    return abs(a - b) / abs(b)
+
+
+# ---- partition_matrix, code/MPI/cg.cc:236-268 ---------------------------------------------------
+@pytest.mark.parametrize("n,p,start,num", [
+    (10, 1, [0], [10]),
+    (10, 2, [0, 5], [5, 5]),
+    (10, 3, [0, 3, 6], [3, 3, 4]),
+    (1000, 3, [0, 333, 666], [333, 333, 334]),
+    (7, 8, [0] * 8, [0] * 7 + [7]),
+    (46340, 8, [5792 * i for i in range(8)], [5792] * 7 + [5796]),
+    (32768, 8, [4096 * i for i in range(8)], [4096] * 8),
+])
+def test_partition_truth_table(oracle, n, p, start, num):
+    s, c = oracle.partition(n, p)
+    assert s == start and c == num
+    assert sum(c) == n
+
+
+# ---- generate_lap2d_matrix, code/MPI/cg.cc:159-188 ---------------------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 9, 10, 16, 17, 100, 1000])
+def test_generator_structure(oracle, n):
+    A = oracle.generate_lap2d(n)
+    inc = int(np.floor(np.sqrt(n)))
+    E = np.zeros((n, n))
+    for i in range(n):   # literal restatement of the five assignments
+        if i > inc: E[i, i - 1 - inc] = -1
+        if i > 0: E[i, i - 1] = -1
+        E[i, i] = 4
+        if i < n - 1: E[i, i + 1] = -1
+        if i < n - 1 - inc: E[i, i + 1 + inc] = -1
+    assert np.array_equal(A, E)
+    assert np.array_equal(A, A.T)                     # symmetric penta-diagonal Toeplitz
+    if n >= 4:
+        assert np.count_nonzero(A[n // 2]) <= 5
+
+
+def test_generator_row_blocks_match_full(oracle):
+    n = 1000
+    A = oracle.generate_lap2d(n)
+    s, c = oracle.partition(n, 3)
+    for r0, nr in zip(s, c):
+        assert np.array_equal(oracle.generate_lap2d(n, r0, nr), A[r0:r0 + nr])
+
+
+# ---- init_source_term, code/MPI/cg.cc:218-234 ---------------------------------------------------------
+def test_source_term_expression(oracle):
+    n = 1024
+    b = oracle.init_source_term(n)
+    h = 1.0 / n
+    import math
+    for i in (0, 1, 7, 511, 1023):
+        e = -2. * i * math.pi * math.pi * math.sin(10. * math.pi * i * h) * math.sin(10. * math.pi * i * h)
+        assert b[i] == e
+    # ||b|| recorded by the survey for the reference
+    assert rel(np.linalg.norm(b), 2.2847e5) < 1e-4
+    assert rel(np.linalg.norm(oracle.init_source_term(10000)), 6.9722e6) < 1e-4
+
+
+# ---- BLAS restatements vs numpy ---------------------------------------------------------------------
+@pytest.mark.parametrize("m,n", [(1, 1), (3, 5), (4, 4), (7, 129), (64, 1000), (333, 1001)])
+def test_gemv_dot_against_numpy(oracle, m, n):
+    rng = np.random.default_rng(m * 1000 + n)
+    A = rng.standard_normal((m, n))
+    x = rng.standard_normal(n)
+    y = oracle.gemv(A, x)
+    assert np.allclose(y, A @ x, rtol=1e-13, atol=1e-13)
+    assert rel(oracle.dot(x, x), float(x @ x)) < 1e-14
+
+
+# ---- solve vs the reference's own outputs -------------------------------------------------------------
+def _fixed_rows(probe):
+    return [r for r in probe["generated"] if r["max_iter"] is not None and r["n"] <= 4096]
+
+
+def test_fixed_iteration_runs_match_reference(oracle, reference_probe):
+    """At a fixed iteration count the reference's printed numbers are reproducible to ~7 digits whatever
+    the BLAS / rank count: the oracle must land on them."""
+    seen = 0
+    for row in _fixed_rows(reference_probe):
+        x, r = oracle.solve_lap2d(row["n"], row["max_iter"], 1e-10, row["ranks"])
+        assert r["iterations"] == row["k"]
+        assert rel(r["residual_prev"], row["residual"]) < 1e-6, row
+        assert rel(r["x_norm"], row["x_norm"]) < 1e-6, row          # printed with 7 digits
+        # ||Ax-b||/||b|| near its rounding floor (~1e-11) moves with the summation order: 2e-4 observed
+        # between MKL and this oracle at n=2048; away from the floor it is reproducible to 6 digits.
+        tol = 1e-5 if row["rel_residual"] > 1e-9 else 1e-2
+        assert rel(r["rel_residual"], row["rel_residual"]) < tol, row
+        seen += 1
+    assert seen >= 8
+
+
+@pytest.mark.parametrize("n,ranks", [(1024, 1), (1024, 2), (1024, 8), (1000, 3), (2048, 1)])
+def test_converged_runs_match_reference(oracle, reference_probe, n, ranks):
+    row = [r for r in reference_probe["generated"] if r["n"] == n and r["ranks"] == ranks and r["max_iter"] is None][0]
+    x, r = oracle.solve_lap2d(n, None, 1e-10, ranks)
+    assert r["converged"] == 1
+    assert abs(r["iterations"] - row["k"]) <= 0.15 * row["k"]        # k is not a stable observable
+    assert r["residual_last"] < 1e-10
+    assert rel(r["x_norm"], row["x_norm"]) < 1e-6
+    assert r["rel_residual"] < 1e-11
+    # break happens before rsold is updated: the printed residual is the previous iteration's (cg.cc:120,152)
+    assert r["residual_prev"] >= 1e-10
+
+
+def test_rank_count_does_not_change_solution(oracle):
+    xs = [oracle.solve_lap2d(2048, 200, 1e-10, p)[0] for p in (1, 2, 3, 8)]
+    for x in xs[1:]:
+        assert np.linalg.norm(x - xs[0]) / np.linalg.norm(xs[0]) < 5e-15   # reference: <= 9e-16
+
+
+def test_large_oracle_runs_pinned_to_reference(reference_probe, oracle_large):
+    """tests/golden/oracle_large.json (oracle at the BASELINE.json sizes, made by make_oracle_large.py)
+    against the reference's recorded outputs incl. sampled solution entries at full precision."""
+    ref = {(r["n"], r["max_iter"]): r for r in reference_probe["generated_large"]}
+    checked = 0
+    for c in oracle_large["cases"]:
+        r = ref.get((c["n"], c["max_iter"]))
+        if r is None:
+            continue
+        assert c["k"] == r["k"]
+        assert rel(c["residual"], r["residual"]) < 1e-6
+        assert rel(c["x_norm"], r["x_norm"]) < 1e-12
+        assert rel(c["rel_residual"], r["rel_residual"]) < 1e-5
+        for i, v in r["x_samples"].items():
+            assert rel(c["x_samples"][i], v) < 1e-12, (c["n"], i)
+        checked += 1
+    assert checked >= 2
+
+
+# ---- Matrix-Market input surface -----------------------------------------------------------------------
+def test_mtx_fixture_is_the_reference_file(mtx_path):
+    ref = os.path.join(REF, "lap2D_5pt_n100.mtx")
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not present on this machine")
+    assert open(mtx_path, "rb").read() == open(ref, "rb").read()
+
+
+def test_mtx_reader(oracle, mtx_path):
+    A, nz, sym = oracle.read_mtx_dense(mtx_path)
+    assert A.shape == (10000, 10000) and nz == 29800 and sym
+    assert np.count_nonzero(A) == 49600                       # after mirroring
+    assert np.array_equal(A, A.T)
+    assert np.all(np.diag(A) == 4.0)
+    rs = A.sum(axis=1)
+    assert rs.min() == 0.0 and rs.max() == 2.0                # interior rows sum to 0, corners to 2
+    # true 5-point stencil: the +-1 band is broken at grid-row boundaries, unlike generate_lap2d_matrix
+    assert A[99, 100] == 0.0 and A[100, 99] == 0.0 and A[0, 100] == -1.0
+
+
+def test_mtx_solve_matches_reference(oracle, mtx_path, reference_probe):
+    A, _, _ = oracle.read_mtx_dense(mtx_path)
+    n = A.shape[0]
+    b = oracle.init_source_term(n)
+    row = reference_probe["mtx_lap2D_5pt_n100"][0]
+    x, r = oracle.solve(A, b, None, 60, 1e-10, 1)             # bounded: 60 iterations ~ 4 s on one core
+    assert r["iterations"] == 60
+    # converged-run anchors need the full ~488 iterations (30 s single core): checked in the GPU suite
+    # against the same golden row; here only sanity of the early iterations.
+    assert r["residual_prev"] > 1.0 and np.isfinite(r["x_norm"])
+    assert row["k"] == 488

@@ -26,11 +26,11 @@ def check_gemv(n, variant, mode=pkg.COMM_SELF, nranks=1):
         print("gemv n=%d variant=%d mode=%d P=%d maxrel=%.2e pAp rel=%.2e" % (n, variant, mode, nranks, err, perr), flush=True)
         assert err < 1e-13 and perr < 1e-12
 
-for v in (0, 1821, 1441, 1241, 1181, 2821, 2441, 2241):
+for v in (0, 10821, 10441, 10241, 10181, 20821, 20441, 20241):
     check_gemv(1000, v)
-check_gemv(1001, 0); check_gemv(777, 2441)
+check_gemv(1001, 0); check_gemv(777, 20441)
 check_gemv(1000, 0, pkg.COMM_LOOPBACK, 3)
-check_gemv(2048, 2441, pkg.COMM_LOOPBACK, 4)
+check_gemv(2048, 20441, pkg.COMM_LOOPBACK, 4)
 
 def solve(n, mi, mode=pkg.COMM_SELF, nranks=1, variant=0):
     with pkg.CGSolver(comm_mode=mode, nranks=nranks, gemv_variant=variant) as s:
@@ -48,7 +48,7 @@ for (n, mi, mode, P) in [(2048, 200, 0, 1), (2048, 200, 1, 4), (1000, None, 1, 3
 
 # K1 sweep at the roofline point
 N = int(os.environ.get("SWEEP_N", "32768"))
-variants = [int(v) for v in os.environ.get("SWEEP_VARIANTS", "1821,1820,1441,1440,1811,1281,2821,2441,2241,2421,2820").split(",")]
+variants = [int(v) for v in os.environ.get("SWEEP_VARIANTS", "10821,10820,10441,10440,10811,10281,20821,20441,20241,20421,20820").split(",")]
 pads = [int(v) for v in os.environ.get("SWEEP_PADS", "0,16").split(",")]
 out = []
 for pad in pads:
