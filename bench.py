@@ -35,7 +35,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)      # BASELINE.json configs[2]: fixed 500 iterations
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n", type=int, default=0, help="matrix size (default 32768; weak mode: floor(16384*sqrt(P)))")
+    ap.add_argument("--matrix-size", dest="n", type=int, default=0, help="matrix size (default 32768; weak mode: floor(16384*sqrt(P)))")
     ap.add_argument("--mode", choices=["strong", "weak"], default="strong")
     ap.add_argument("--variant", type=int, default=0, help="K1 shape override (DESIGN.md)")
     ap.add_argument("--lda-pad", type=int, default=-1)
@@ -100,12 +100,19 @@ def main():
     import __graft_entry__ as g
 
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path to time"
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev:
+        # more ranks than GPUs is only ever a rehearsal on a one-GPU box (RCCL itself refuses duplicate devices)
+        local_rank = local_rank % ndev
     torch.cuda.set_device(local_rank)
     pkg = g.load_package()
 
     dist = None
     uid = None
-    if world > 1:
+    # Under torch.distributed.run (RANK set) the RCCL path is used even for one rank, so that the launcher
+    # plumbing and the collectives can be rehearsed on a one-GPU box; plain `python bench.py` has no comm.
+    use_comm = world > 1 or ("RANK" in os.environ and os.environ.get("CGX_BENCH_FORCE_SELF") != "1")
+    if use_comm:
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
@@ -119,7 +126,7 @@ def main():
     else:
         n = 32768
 
-    solver = pkg.CGSolver(comm_mode=pkg.COMM_RCCL if world > 1 else pkg.COMM_SELF, nranks=world, rank=rank,
+    solver = pkg.CGSolver(comm_mode=pkg.COMM_RCCL if use_comm else pkg.COMM_SELF, nranks=world, rank=rank,
                           device=local_rank, unique_id=uid, gemv_variant=args.variant, lda_pad=args.lda_pad,
                           profile_gemv=not args.no_profile_gemv)
     solver.generate_lap2d_matrix(n)
@@ -177,7 +184,7 @@ def main():
                 "workload": "generate_lap2d_matrix N=%d, init_source_term(1/N), fixed-iteration dense fp64 CG "
                             "(BASELINE.json configs[%d])" % (n, 2 if world == 1 else (3 if args.mode == "strong" else 4)),
                 "n": n, "rows_per_gpu": rows0, "parallelism": "rowblock%d" % world,
-                "collectives": "none" if world == 1 else "RCCL allgather(scalars) x2 + allgather(p) per iteration",
+                "collectives": "RCCL allgather(scalars) x2 + allgather(p) per iteration" if use_comm else "none",
                 "k1_variant": args.variant,
             },
             "roofline": {
