@@ -34,7 +34,7 @@ def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=500)      # BASELINE.json configs[2]: fixed 500 iterations
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=100)   # ~0.12 s: lets the clocks settle before the timed region
     ap.add_argument("--matrix-size", dest="n", type=int, default=0, help="matrix size (default 32768; weak mode: floor(16384*sqrt(P)))")
     ap.add_argument("--mode", choices=["strong", "weak"], default="strong")
     ap.add_argument("--variant", type=int, default=0, help="K1 shape override (DESIGN.md)")
@@ -42,6 +42,9 @@ def parse_args():
     ap.add_argument("--cpu-baseline-iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-gemv", action="store_true", help="do not bracket K1 with HIP events")
+    ap.add_argument("--profile-every", type=int, default=0,
+                    help="event-time every n-th K1 launch (default: 1 on one GPU, 8 on several: the event pair "
+                         "costs ~10 us per timed launch)")
     return ap.parse_args()
 
 
@@ -128,7 +131,7 @@ def main():
 
     solver = pkg.CGSolver(comm_mode=pkg.COMM_RCCL if use_comm else pkg.COMM_SELF, nranks=world, rank=rank,
                           device=local_rank, unique_id=uid, gemv_variant=args.variant, lda_pad=args.lda_pad,
-                          profile_gemv=not args.no_profile_gemv)
+                          profile_gemv=0 if args.no_profile_gemv else (args.profile_every or (1 if world == 1 else 8)))
     solver.generate_lap2d_matrix(n)
     solver.set_max_iter(args.warmup + args.steps)
     solver.tolerance(0.0)                  # fixed-iteration run: the break of cg.cc:120 is never taken

@@ -21,7 +21,7 @@ EXPORTS = [
     "cgx_partition", "cgx_generate_lap2d_matrix", "cgx_set_matrix_dense", "cgx_read_matrix",
     "cgx_init_source_term", "cgx_set_source_term", "cgx_set_max_iter", "cgx_set_tolerance", "cgx_get_size",
     "cgx_solve", "cgx_solve_begin", "cgx_solve_steps", "cgx_solve_end",
-    "cgx_probe_gemv", "cgx_probe_vector_ops", "cgx_probe_get_matrix_rows",
+    "cgx_probe_gemv", "cgx_probe_time_gemv", "cgx_probe_vector_ops", "cgx_probe_get_matrix_rows",
 ]
 
 
@@ -97,6 +97,7 @@ def lib():
         L.cgx_solve_steps.argtypes = [vp, C.c_int, ip]
         L.cgx_solve_end.argtypes = [vp, dp, C.POINTER(Result)]
         L.cgx_probe_gemv.argtypes = [vp, dp, dp, dp]
+        L.cgx_probe_time_gemv.argtypes = [vp, C.c_int, dp]
         L.cgx_probe_vector_ops.argtypes = [vp, C.c_int, C.c_double, C.c_double, dp, dp, dp, dp, dp]
         L.cgx_probe_get_matrix_rows.argtypes = [vp, C.c_int, dp, ip, ip]
         for name in EXPORTS:
@@ -148,7 +149,7 @@ class CGSolver:
         cfg.gemv_variant = gemv_variant
         cfg.lda_pad = lda_pad
         cfg.check_every = check_every
-        cfg.profile_gemv = 1 if profile_gemv else 0
+        cfg.profile_gemv = int(profile_gemv)   # n > 0: every n-th K1 launch is event-timed
         if unique_id is not None:
             assert len(unique_id) == UNIQUE_ID_BYTES
             C.memmove(cfg.unique_id, bytes(unique_id), UNIQUE_ID_BYTES)
@@ -249,6 +250,11 @@ class CGSolver:
         pap = C.c_double()
         self._check(lib().cgx_probe_gemv(self._h, _dp(p), _dp(y), C.byref(pap)))
         return y, pap.value
+
+    def probe_time_gemv(self, reps=20):
+        ms = C.c_double()
+        self._check(lib().cgx_probe_time_gemv(self._h, int(reps), C.byref(ms)))
+        return ms.value
 
     def probe_vector_ops(self, alpha, beta, x, r, p, Ap):
         x, r, p = (np.array(v, dtype=np.float64, copy=True) for v in (x, r, p))

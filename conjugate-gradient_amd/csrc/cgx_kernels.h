@@ -6,24 +6,41 @@
 
 namespace cgx {
 
-// Device-resident scalar block of one shard.  Nothing in the iteration loop is read back by the
-// host except `done` (polled every check_every iterations).
-struct Scalars {
-    double rs[2];        // rsold / rsnew ping-pong: iteration k reads rs[k&1], writes rs[(k+1)&1]   (cg.cc:91,116,132)
-    double local[4];     // this shard's contributions to the reductions (all-gather send buffer, kSlots doubles)
-    double dbg[4];       // global ||Ax-b||^2, ||b||^2, ||x||^2 (cg.cc:145-151)
-    int    done;         // set by K4 when sqrt(rsnew) < tol (cg.cc:120-121); later kernels exit at once
-    int    k_final;      // k of the converging iteration
-    int    pad[2];
-};
-
-// Scalar exchange: every shard all-gathers its `local[kSlots]`; consumers sum slot v over ranks in rank
-// order (bit-identical on every shard, which is what makes all ranks take the same break, cg.cc:117-121).
+// Scalar exchange: every shard publishes kSlots doubles; consumers sum slot v over ranks in rank order
+// (bit-identical on every shard, which is what makes all ranks take the same break, cg.cc:117-121).
 constexpr int kSlots = 4;
 constexpr int kSlotConj = 0;   // p.Ap partial              (cg.cc:105-106); DEBUG: ||Ax-b||^2
 constexpr int kSlotRr = 1;     // r.r partial               (cg.cc:116-117, 91-92); DEBUG: ||b||^2
 constexpr int kSlotX = 2;      // DEBUG: ||x||^2            (cg.cc:151)
 constexpr int kMaxRanks = 64;  // gathered[] holds kMaxRanks*kSlots doubles
+
+// Device-resident scalar block of one shard.  Nothing in the iteration loop is read back by the
+// host except `done` (polled every check_every iterations).
+struct Scalars {
+    double rs[2];          // rsold / rsnew ping-pong: rs[k&1] is rsold of iteration k          (cg.cc:91,116,132)
+    double local[kSlots];  // this shard's p.Ap partial etc.: send buffer of the small all-gather
+    double dbg[4];
+    int    done;           // set when sqrt(rsnew) < tol (cg.cc:120-121); later kernels exit at once
+    int    k_final;        // k of the converging iteration
+    unsigned counter[2];   // arrival tickets of the in-kernel reductions of K1 / K3 (always 0 between launches)
+};
+
+// The exchanged residual: P equal segments of S doubles, segment q = [ r slice of rank q (Sr doubles,
+// zero padded) | kSlots scalars of rank q ].  One in-place all-gather of S doubles per rank moves r AND
+// r.r together (MPI_Allgatherv + MPI_Allreduce of cg.cc:117,135-136 in one message).
+struct SegView {
+    double *base;     // this shard's copy of all P segments
+    int S, Sr;        // segment stride, r part
+    int n_loc;        // floor(n / nranks): rows of every rank but the last (cg.cc:255)
+    int nranks;
+    int n;
+    int rank;         // this shard
+    int seg_gap;      // S - n_loc: r[c] of owner q sits at base[c + q*seg_gap]
+    unsigned div_magic, div_shift;   // c / n_loc == umulhi(c, div_magic) >> div_shift for 0 <= c < 2^31
+};
+
+// Fill seg_gap and the division magic of a SegView whose S, n_loc, nranks are set.
+void seg_finalize(SegView *sv);
 
 struct GemvPlan {
     int variant;     // 1 = column-split (p from L2 to registers), 2 = row-split (p tiles staged in LDS)
@@ -38,36 +55,44 @@ struct GemvPlan {
 // Choose the K1 shape for a shard of `rows` x `ncols` (variant 0 = default).
 GemvPlan plan_gemv(int variant, int rows, int ncols);
 
-// K1: Ap = A[rows x lda] * p ; partials[wg] = sum over the workgroup's rows of p_local[row]*Ap[row].
-// `done` may be null.  cblas_dgemv + cblas_ddot of code/MPI/cg.cc:100-105.
-hipError_t launch_gemv(const GemvPlan &plan, const double *A, long lda, int rows, const double *p_full,
-                       const double *p_local, double *Ap, double *partials, const int *done, hipStream_t s);
+// K1, plain form: Ap = A[rows x lda] * v ; partials[wg] = sum over the workgroup's rows of v_local[i]*Ap[i].
+// Used for the initial residual (cg.cc:79-81), the DEBUG verification (cg.cc:146-147) and the probes.
+hipError_t launch_gemv_plain(const GemvPlan &plan, const double *A, long lda, int rows, const double *v_full,
+                             const double *v_local, double *Ap, double *partials, Scalars *sc, hipStream_t s);
 
-// K2: out[0] = deterministic sum of partials[0..n).
-hipError_t launch_reduce_partials(const double *partials, int n, double *out, const int *done, hipStream_t s);
+// K1, fused form = body of iteration k up to p.Ap (cg.cc:100-105) preceded by the tail of iteration k-1
+// (cg.cc:117-132): rsnew = sum of the gathered r.r; convergence test; beta; p_new = r + beta p_old computed
+// on the fly for every column (and stored once), Ap = A p_new, partials[wg] = the workgroup's part of p_new_local . Ap.
+hipError_t launch_gemv_fused(const GemvPlan &plan, const double *A, long lda, int rows, int row0,
+                             const double *p_old, double *p_new, SegView seg, double *Ap, double *partials,
+                             Scalars *sc, int k, double tol, hipStream_t s);
 
-// K3: alpha = rsold / max(conj, rsold*1e-14); x += alpha p; r -= alpha Ap; partials[wg] = sum r_i^2.
-// conj = sum_{q<nranks} gathered[q].  cg.cc:107-116.
-hipError_t launch_update_xr(int count, const double *p_local, const double *Ap, double *x, double *r,
-                            const Scalars *sc, int parity, const double *gathered, int nranks,
-                            double *partials, hipStream_t s);
+// K3: conj = fixed-order sum of gathered[0..ngathered) (all ranks' K1 partials); alpha = rsold / max(conj,
+// rsold*1e-14); x += alpha p; r -= alpha Ap (r lives in this shard's segment); segment scalar slot kSlotRr =
+// sum r_i^2 (in-kernel reduction by the last-arriving workgroup).  cg.cc:105-116.
+hipError_t launch_update_xr(int count, const double *p_local, const double *Ap, double *x, SegView seg,
+                            Scalars *sc, int parity, const double *gathered, int ngathered, double *partials,
+                            hipStream_t s);
 int update_xr_grid(int count);
 
-// K4: rsnew = sum gathered[q] -> rs[(k+1)&1]; if sqrt(rsnew) < tol: done=1, k_final=k, return;
-// else beta = rsnew/rsold; p_local = r + beta*p_local.  cg.cc:117-132.
-hipError_t launch_update_p(int count, const double *r, double *p_local, Scalars *sc, int parity, int k,
-                           double tol, const double *gathered, int nranks, hipStream_t s);
+// Tail of the LAST executed iteration when the loop runs out (k = number of iterations done):
+// rsnew -> rs[k&1], convergence test (cg.cc:117-121,132).  One thread.
+hipError_t launch_close_iteration(Scalars *sc, SegView seg, int k, double tol, hipStream_t s);
 
-// Initial residual pieces (cg.cc:79-92): r = b - Ap ; p_local = r ; partials[wg] = sum r_i^2.
-hipError_t launch_init_residual(int count, const double *b, const double *Ap, double *r, double *p_local,
-                                double *partials, hipStream_t s);
-// rs[0] = rs[1] = sum over ranks of slot kSlotRr; done = 0.
-hipError_t launch_set_rsold(Scalars *sc, const double *gathered, int nranks, hipStream_t s);
+// K2: out[0..NV) = deterministic sum of partials (stand-alone form, setup/verification only).
+hipError_t launch_reduce_partials(const double *partials, int n, double *out, hipStream_t s);
+hipError_t launch_reduce_partials3(const double *partials, int n, double *out3, hipStream_t s);
+
+// Initial residual (cg.cc:79-85): r = b - Ap into this shard's segment; partials[wg] = sum r_i^2.
+hipError_t launch_init_residual(int count, const double *b, const double *Ap, SegView seg, double *partials,
+                                hipStream_t s);
+
+// v_full[c] = segment value of column c (c < n), 0 for the pad: turns gathered slices into a replicated vector.
+hipError_t launch_unpack_segments(SegView seg, double *v_full, long lda, hipStream_t s);
 
 // DEBUG block (cg.cc:144-151): partials[3*wg + {0,1,2}] = sum (Ax-b)^2, b^2, x^2 over this shard's rows.
 hipError_t launch_debug_norms(int count, const double *Ax, const double *b, const double *x, double *partials,
                               hipStream_t s);
-hipError_t launch_reduce_partials3(const double *partials, int n, double *out3, hipStream_t s);
 
 // generate_lap2d_matrix (cg.cc:159-188) for rows [row0,row0+rows) straight into device memory; pad columns = 0.
 hipError_t launch_generate_lap2d(double *A, long lda, int size, int row0, int rows, hipStream_t s);

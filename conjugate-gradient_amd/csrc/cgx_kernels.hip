@@ -1,16 +1,29 @@
 // cgx_kernels.hip -- hand-written CDNA4 (gfx950, wave64) kernels of the dense fp64 CG hot path.
 //
-// The path restated here is CGSolver::solve's loop body, code/MPI/cg.cc:96-137 (reference file:line):
-//   K1 gemv       cblas_dgemv  cg.cc:100-102   + fused cblas_ddot(p_sub, Ap_sub) cg.cc:105
-//   K2 reduce     the local half of MPI_Allreduce, cg.cc:106,117
-//   K3 update_xr  alpha cg.cc:107, two cblas_daxpy cg.cc:110,113, cblas_ddot(r,r) cg.cc:116
-//   K4 update_p   convergence test cg.cc:120-121, beta cg.cc:124, p = r + beta p cg.cc:127-129, rsold = rsnew cg.cc:132
-// None of it is derived from code/CUDA/cg.cu: that file uses thread-per-row-chunk kernels with
-// atomicAdd; these are streaming kernels without atomics, deterministic for a fixed launch shape.
+// The path restated here is CGSolver::solve's loop body, code/MPI/cg.cc:96-137 (reference file:line).
+// One iteration k is TWO kernels and TWO exchanges:
 //
-// Everything is HBM-bound (0.25 flop/byte): no MFMA.  What matters is 16 B/lane coalesced loads of
-// A's rows, enough independent loads in flight per CU, p served from L2/LDS instead of HBM, and
-// keeping every scalar on the device.
+//   K1 gemv_fused   tail of iteration k-1:  rsnew = allreduce(r.r)              cg.cc:117
+//                                           if sqrt(rsnew) < tol: break          cg.cc:120-121
+//                                           beta = rsnew/rsold                   cg.cc:124
+//                                           p = r + beta p   (on the fly)        cg.cc:127-129
+//                                           rsold = rsnew                        cg.cc:132
+//                   head of iteration k:    Ap = A_sub p                         cg.cc:100-102 (cblas_dgemv)
+//                                           local p_sub.Ap_sub                   cg.cc:105     (cblas_ddot)
+//   -- exchange 1: all-gather of kSlots doubles (the p.Ap partials)              cg.cc:106     (MPI_Allreduce)
+//   K3 update_xr    alpha                                                        cg.cc:107
+//                   x += alpha p ; r -= alpha Ap ; local r.r                     cg.cc:110,113,116
+//   -- exchange 2: all-gather of [r slice | r.r partial]                         cg.cc:117 + 135-136
+//
+// Fusing the p update into the GEMV means the vector that travels between ranks is r, not p: every rank
+// recomputes p = r + beta p for all N columns while it streams them for the GEMV anyway (bitwise the
+// same value everywhere), so the reference's third collective and its separate update kernel disappear.
+// None of this is derived from code/CUDA/cg.cu (thread-per-row-chunk kernels with atomicAdd); these are
+// streaming kernels without floating-point atomics, deterministic for a fixed launch shape.
+//
+// Everything is HBM-bound (0.25 flop/byte): no MFMA.  What matters is 16 B/lane coalesced loads of A's
+// rows, enough independent loads in flight per CU, p/r served from L2/LDS instead of HBM, and keeping
+// every scalar on the device.
 #include "cgx_kernels.h"
 
 namespace cgx {
@@ -18,6 +31,8 @@ namespace cgx {
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 static constexpr double kNearZero = 1.0e-14;   // NEARZERO, code/MPI/cg.cc:8
+
+#define CGX_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 // ------------------------------------------------------------------------------------------------
 // reductions: fixed order => bitwise reproducible for a given launch shape
@@ -43,6 +58,44 @@ __device__ __forceinline__ double block_sum(double v, double *lds /* >= WAVES do
     return s;
 }
 
+// Grid-wide sum of one double per workgroup without a second launch: every workgroup publishes its
+// partial write-through (sc1 store), drains, and takes a ticket; the workgroup that draws the last
+// ticket folds all partials in index order (so the result does not depend on arrival order) and resets
+// the ticket word.  This is the counter form of the agent-scope hand-off (cdna_hip_programming.md
+// Guideline 16 / MI355X_MICROARCH.md "Valid forms", first table row): sc1 payload stores, every storing
+// lane's s_waitcnt vmcnt(0) before its own atomic add, last arriver told by the add's return value,
+// sc1 loads of the payload; the agent-scope acquire is kept as well.
+template <int WAVES>
+__device__ __forceinline__ void grid_sum_last_arriver(double d /* thread 0 */, double *partials, unsigned *counter,
+                                                      double *out, double *lds, int *s_flag)
+{
+    const unsigned nwg = gridDim.x;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(partials) + blockIdx.x,
+                           (unsigned long long)__double_as_longlong(d), CGX_RLX_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(counter, 1u, CGX_RLX_AGENT);
+        *s_flag = (t == nwg - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (*s_flag) {   // workgroup-uniform
+        if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        double s = 0.0;
+        for (unsigned i = threadIdx.x; i < nwg; i += WAVES * 64)
+            s += __longlong_as_double((long long)__hip_atomic_load(
+                reinterpret_cast<unsigned long long *>(partials) + i, CGX_RLX_AGENT));
+        s = block_sum<WAVES>(s, lds);
+        if (threadIdx.x == 0) {
+            *out = s;
+            __hip_atomic_store(counter, 0u, CGX_RLX_AGENT);
+        }
+    }
+}
+
+enum { kPlain = 0, kFusedSingle = 1, kFusedMulti = 2 };
+
 template <bool NT>
 __device__ __forceinline__ d2 load_a(const double *ptr)
 {
@@ -51,34 +104,122 @@ __device__ __forceinline__ d2 load_a(const double *ptr)
 }
 
 // ------------------------------------------------------------------------------------------------
+// the exchanged residual (SegView) and the scalar sums over ranks
+// ------------------------------------------------------------------------------------------------
+// Owner of column c: q = min(c / n_loc, nranks-1), without an integer division: the host supplies the
+// round-up magic number (div_magic, div_shift) for n_loc (seg_finalize), exact for 0 <= c < 2^31.
+__device__ __forceinline__ int seg_owner(const SegView &sv, int c)
+{
+    const int t = (sv.div_shift == 32) ? c : (int)(__umulhi((unsigned)c, sv.div_magic) >> sv.div_shift);
+    return t < sv.nranks - 1 ? t : sv.nranks - 1;
+}
+
+__device__ __forceinline__ double seg_load(const SegView &sv, int c)   // r[c], c < n
+{
+    const int q = (sv.nranks > 1) ? seg_owner(sv, c) : 0;
+    return sv.base[c + q * sv.seg_gap];   // q*S + (c - q*n_loc)
+}
+
+__device__ __forceinline__ double seg_sum_slot(const SegView &sv, int slot)
+{
+    double s = sv.base[sv.Sr + slot];
+    for (int q = 1; q < sv.nranks; ++q) s += sv.base[(long)q * sv.S + sv.Sr + slot];   // rank order
+    return s;
+}
+
+// gathered layout on every shard: [rank q][slot v], kSlots doubles per rank
+__device__ __forceinline__ double sum_ranks(const double *__restrict__ gathered, int slot, int nranks)
+{
+    double s = gathered[slot];
+    for (int q = 1; q < nranks; ++q) s += gathered[q * kSlots + slot];   // rank order, same on every shard
+    return s;
+}
+
+// Tail of iteration k-1, evaluated redundantly (and identically) by every thread of K1(k).
+struct IterHead {
+    double beta;
+    bool stop;
+};
+
+__device__ __forceinline__ IterHead iteration_head(Scalars *sc, const SegView &sv, int k, double tol)
+{
+    IterHead h{0.0, false};
+    const double rsnew = seg_sum_slot(sv, kSlotRr);                  // MPI_Allreduce, cg.cc:117 (k==0: cg.cc:92)
+    const bool first = (blockIdx.x == 0 && threadIdx.x == 0);
+    if (k == 0) {                                                    // p = r (cg.cc:85): beta = 0, p_old = 0
+        if (first) { sc->rs[0] = rsnew; sc->rs[1] = rsnew; }
+        return h;
+    }
+    const double rsold = sc->rs[(k - 1) & 1];
+    if (first) sc->rs[k & 1] = rsnew;                                // rsold = rsnew, cg.cc:132
+    if (sqrt(rsnew) < tol) {                                         // cg.cc:120-121: break before the p update
+        if (first) { sc->k_final = k - 1; sc->done = 1; }
+        h.stop = true;
+        return h;
+    }
+    h.beta = rsnew / rsold;                                          // cg.cc:124
+    return h;
+}
+
+// p_new for the column pair (c, c+1); pad columns (>= n) stay exactly 0.
+// SINGLE (one shard): r is contiguous and zero padded up to lda, one 16-B load.
+template <bool SINGLE>
+__device__ __forceinline__ d2 make_p(const SegView &sv, double beta, d2 p_old, int c)
+{
+    d2 r;
+    if constexpr (SINGLE) {
+        r = *reinterpret_cast<const d2 *>(sv.base + c);
+    } else {
+        r.x = (c < sv.n) ? seg_load(sv, c) : 0.0;
+        r.y = (c + 1 < sv.n) ? seg_load(sv, c + 1) : 0.0;
+    }
+    d2 p;
+    p.x = fma(beta, p_old.x, r.x);                                   // cg.cc:127-129
+    p.y = fma(beta, p_old.y, r.y);
+    return p;
+}
+
+// ------------------------------------------------------------------------------------------------
 // K1, variant 1: column-split.  One workgroup owns R consecutive rows; its WAVES waves split the
 // columns in 1 KiB pieces (lane = 16 B), so every global_load_dwordx4 of A is a fully coalesced
-// 1 KiB wave access and the workgroup sweeps WAVES KiB of each row per step.  p is loaded once per
-// step (16 B/lane, L2 hit) and reused from registers by all R rows: p traffic = 1/R of A traffic.
-// U steps are issued back to back: R*U independent 1 KiB loads in flight per wave.
-// Epilogue: DPP/shuffle wave reduction, LDS cross-wave combine in fixed wave order, Ap store, and the
-// fused p.Ap partial of the workgroup's rows (cg.cc:105).
+// 1 KiB wave access and the workgroup sweeps WAVES KiB of each row per step.  The vector is loaded once
+// per step (16 B/lane, L2 hit) and reused from registers by all R rows: vector traffic = 1/R of the A
+// stream.  U steps are issued back to back: R*U independent 1 KiB loads in flight per wave.
+// Epilogue: shuffle wave reduction, LDS cross-wave combine in fixed wave order, Ap store, and the
+// fused p.Ap (cg.cc:105) reduced over the grid by the last-arriving workgroup.
+// FUSED: the vector is p_new = r + beta p_old, formed in registers from two L2-resident streams; the
+// workgroup whose turn it is (step index mod grid) also stores it, so p_new is written exactly once.
 // ------------------------------------------------------------------------------------------------
-template <int R, int U, int WAVES, bool NT>
+template <int R, int U, int WAVES, int MODE>
 __global__ __launch_bounds__(WAVES * 64) void k_gemv_colsplit(const double *__restrict__ A, long lda, int rows,
-                                                               const double *__restrict__ p,
-                                                               const double *__restrict__ p_local,
-                                                               double *__restrict__ Ap, double *__restrict__ partials,
-                                                               const int *__restrict__ done)
+                                                               int row0_global, const double *__restrict__ v,
+                                                               double *__restrict__ p_new, SegView sv,
+                                                               double *__restrict__ Ap, double *partials,
+                                                               Scalars *sc, int k, double tol)
 {
-    if (done && *done) return;   // converged earlier: the whole grid drains immediately
+    constexpr bool FUSED = MODE != kPlain;
+    constexpr bool SINGLE = MODE == kFusedSingle;
+    constexpr bool NT = true;   // A is streamed once: non-temporal loads keep p and r in L2 (+12 % measured)
+    double beta = 0.0;
+    if constexpr (FUSED) {
+        if (sc->done) return;   // converged earlier: the whole grid drains immediately
+        const IterHead h = iteration_head(sc, sv, k, tol);
+        if (h.stop) return;
+        beta = h.beta;
+    }
     __shared__ double red[WAVES][R];
 
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const long row0 = (long)blockIdx.x * R;
-    const int ncols = (int)lda;   // pad columns hold zeros in A and in p
+    const int ncols = (int)lda;   // pad columns hold zeros in A and in the vector
 
     const double *a[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         long row = row0 + r;
         if (row > rows - 1) row = rows - 1;   // tail workgroup: re-read the last row, result discarded
+        if (row < 0) row = 0;                 // shard without rows (N < P): stream the dummy row, store nothing
         a[r] = A + row * lda;
     }
     double acc0[R], acc1[R];
@@ -87,18 +228,32 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_colsplit(const double *__re
 
     constexpr int kStep = WAVES * 128;   // doubles swept by the workgroup per step
     int c = w * 128 + lane * 2;
-    for (; c + (U - 1) * kStep < ncols; c += U * kStep) {
+    int step = 0;                        // index of the step this trip starts with
+    int my_step = (int)blockIdx.x;       // next step whose p_new this workgroup stores
+    for (; c + (U - 1) * kStep < ncols; c += U * kStep, step += U) {
         d2 pv[U];
         d2 av[U][R];
 #pragma unroll
-        for (int u = 0; u < U; ++u) pv[u] = *reinterpret_cast<const d2 *>(p + c + u * kStep);
+        for (int u = 0; u < U; ++u) pv[u] = *reinterpret_cast<const d2 *>(v + c + u * kStep);
+        if constexpr (FUSED) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) pv[u] = make_p<SINGLE>(sv, beta, pv[u], c + u * kStep);
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int r = 0; r < R; ++r) av[u][r] = load_a<NT>(a[r] + c + u * kStep);
-        // Keep all R*U+U loads in flight: without this fence hipcc's occupancy-driven scheduler
+        // Keep all R*U loads in flight: without this fence hipcc's occupancy-driven scheduler
         // re-serialises them as load / s_waitcnt vmcnt(0) / fma pairs (measured in the .s).
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr (FUSED) {
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (step + u == my_step) {
+                    *reinterpret_cast<d2 *>(p_new + c + u * kStep) = pv[u];
+                    my_step += (int)gridDim.x;
+                }
+        }
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
@@ -107,14 +262,25 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_colsplit(const double *__re
                 acc1[r] = fma(av[u][r].y, pv[u].y, acc1[r]);
             }
     }
-    for (; c < ncols; c += kStep) {   // remaining single steps (lda is even, so c+1 < lda)
-        d2 pv = *reinterpret_cast<const d2 *>(p + c);
+    for (; c < ncols; c += kStep, ++step) {   // remaining single steps (lda is even, so c+1 < lda)
+        d2 pv = *reinterpret_cast<const d2 *>(v + c);
+        if constexpr (FUSED) {
+            pv = make_p<SINGLE>(sv, beta, pv, c);
+            if (step == my_step) {
+                *reinterpret_cast<d2 *>(p_new + c) = pv;
+                my_step += (int)gridDim.x;
+            }
+        }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             d2 av = load_a<NT>(a[r] + c);
             acc0[r] = fma(av.x, pv.x, acc0[r]);
             acc1[r] = fma(av.y, pv.y, acc1[r]);
         }
+    }
+    if constexpr (FUSED) {
+        // steps past this workgroup's last column (possible only for lanes beyond lda): nothing to store.
+        // Steps owned by workgroups that do not exist cannot occur: my_step walks all residues mod grid.
     }
 
 #pragma unroll
@@ -123,8 +289,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_colsplit(const double *__re
         if (lane == 0) red[w][r] = s;
     }
     __syncthreads();
+    double d = 0.0;
     if (w == 0) {
-        double d = 0.0;
         if (lane < R) {
             double s = red[0][lane];
 #pragma unroll
@@ -132,30 +298,45 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_colsplit(const double *__re
             const long row = row0 + lane;
             if (row < rows) {
                 Ap[row] = s;
-                d = p_local[row] * s;
+                const int j = row0_global + (int)row;
+                double pl = v[j];
+                if constexpr (FUSED) pl = fma(beta, pl, seg_load(sv, j));   // same bits as the stored p_new[j]
+                d = pl * s;                                                 // cg.cc:105
             }
         }
         d = wave_sum(d);
+        // One partial per workgroup; K3 folds all of them (all ranks') in a fixed order.  No ticket here:
+        // 4096 workgroups taking a returning atomic on one word cost 3-10 % of K1 (measured).
         if (lane == 0) partials[blockIdx.x] = d;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K1, variant 2: row-split with LDS-staged p.  Each of the WAVES waves owns R rows (the workgroup
-// WAVES*R rows) and all waves sweep the same columns, so the p tile (TILE doubles) is fetched from
-// L2 once per workgroup into LDS (double buffered, one barrier per tile) and read back with
-// conflict-free ds_read_b128 (lane = 16 B).  p traffic from L2 = 1/(WAVES*R) of A traffic.  No cross-wave
-// combine: each wave finishes its own rows with a shuffle reduction.
+// K1, variant 2: row-split with LDS-staged vector tiles.  Each of the WAVES waves owns R rows (the
+// workgroup WAVES*R rows) and all waves sweep the same columns, so the vector tile (TILE doubles) is
+// fetched from L2 once per workgroup into LDS (double buffered, one barrier per tile) and read back
+// with conflict-free ds_read_b128 (lane = 16 B).  L2->CU vector traffic = 1/(WAVES*R) of the A stream.
+// FUSED: the staging threads form p_new = r + beta p_old on the way into LDS; the workgroup whose turn
+// it is (tile index mod grid) also stores the tile to p_new.
 // ------------------------------------------------------------------------------------------------
-template <int R, int U, int WAVES, bool NT>
+template <int R, int U, int WAVES, int MODE>
 __global__ __launch_bounds__(WAVES * 64) void k_gemv_ldsp(const double *__restrict__ A, long lda, int rows,
-                                                           const double *__restrict__ p,
-                                                           const double *__restrict__ p_local,
-                                                           double *__restrict__ Ap, double *__restrict__ partials,
-                                                           const int *__restrict__ done)
+                                                           int row0_global, const double *__restrict__ v,
+                                                           double *__restrict__ p_new, SegView sv,
+                                                           double *__restrict__ Ap, double *partials,
+                                                           Scalars *sc, int k, double tol)
 {
-    if (done && *done) return;
-    constexpr int TILE = 2048;                       // doubles of p per LDS buffer (16 KiB)
+    constexpr bool FUSED = MODE != kPlain;
+    constexpr bool SINGLE = MODE == kFusedSingle;
+    constexpr bool NT = true;
+    double beta = 0.0;
+    if constexpr (FUSED) {
+        if (sc->done) return;
+        const IterHead h = iteration_head(sc, sv, k, tol);
+        if (h.stop) return;
+        beta = h.beta;
+    }
+    constexpr int TILE = 2048;                       // doubles of the vector per LDS buffer (16 KiB)
     constexpr int kThreads = WAVES * 64;
     constexpr int kPerThread = TILE / 2 / kThreads;  // 16-B pieces each thread stages per tile
     static_assert(TILE % (2 * kThreads) == 0, "tile must split evenly");
@@ -172,6 +353,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_ldsp(const double *__restri
     for (int r = 0; r < R; ++r) {
         long row = row0 + r;
         if (row > rows - 1) row = rows - 1;
+        if (row < 0) row = 0;
         a[r] = A + row * lda;
     }
     double acc0[R], acc1[R];
@@ -179,29 +361,43 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_ldsp(const double *__restri
     for (int r = 0; r < R; ++r) { acc0[r] = 0.0; acc1[r] = 0.0; }
 
     const int ntiles = (ncols + TILE - 1) / TILE;
+    int my_tile = (int)blockIdx.x;                   // next tile whose p_new this workgroup stores
     d2 stage[kPerThread];
-    // prologue: tile 0 -> LDS buffer 0
+    auto fetch_tile = [&](int t) {
 #pragma unroll
-    for (int i = 0; i < kPerThread; ++i) {
-        int c = (i * kThreads + threadIdx.x) * 2;
-        stage[i] = (c < ncols) ? *reinterpret_cast<const d2 *>(p + c) : d2{0.0, 0.0};
-    }
+        for (int i = 0; i < kPerThread; ++i) {
+            const int c = t * TILE + (i * kThreads + (int)threadIdx.x) * 2;
+            d2 x = (c < ncols) ? *reinterpret_cast<const d2 *>(v + c) : d2{0.0, 0.0};
+            if constexpr (FUSED) {
+                if (c < ncols) x = make_p<SINGLE>(sv, beta, x, c);
+            }
+            stage[i] = x;
+        }
+    };
+    auto commit_tile = [&](int t, int buf) {
 #pragma unroll
-    for (int i = 0; i < kPerThread; ++i)
-        *reinterpret_cast<d2 *>(&ptile[0][(i * kThreads + threadIdx.x) * 2]) = stage[i];
+        for (int i = 0; i < kPerThread; ++i)
+            *reinterpret_cast<d2 *>(&ptile[buf][(i * kThreads + (int)threadIdx.x) * 2]) = stage[i];
+        if constexpr (FUSED) {
+            if (t == my_tile) {
+#pragma unroll
+                for (int i = 0; i < kPerThread; ++i) {
+                    const int c = t * TILE + (i * kThreads + (int)threadIdx.x) * 2;
+                    if (c < ncols) *reinterpret_cast<d2 *>(p_new + c) = stage[i];
+                }
+                my_tile += (int)gridDim.x;
+            }
+        }
+    };
+    fetch_tile(0);
+    commit_tile(0, 0);
     __syncthreads();
 
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
         const int base = t * TILE;
-        // issue the next tile's p loads early; they land in registers while this tile streams A
-        if (t + 1 < ntiles) {
-#pragma unroll
-            for (int i = 0; i < kPerThread; ++i) {
-                int c = base + TILE + (i * kThreads + threadIdx.x) * 2;
-                stage[i] = (c < ncols) ? *reinterpret_cast<const d2 *>(p + c) : d2{0.0, 0.0};
-            }
-        }
+        // issue the next tile's vector loads early; they land in registers while this tile streams A
+        if (t + 1 < ntiles) fetch_tile(t + 1);
         const int cend = (base + TILE < ncols) ? TILE : (ncols - base);   // valid doubles in this tile (even)
         int c = lane * 2;
         for (; c + (U - 1) * 128 < cend; c += U * 128) {
@@ -231,11 +427,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_ldsp(const double *__restri
                 acc1[r] = fma(av.y, pv.y, acc1[r]);
             }
         }
-        if (t + 1 < ntiles) {
-#pragma unroll
-            for (int i = 0; i < kPerThread; ++i)
-                *reinterpret_cast<d2 *>(&ptile[buf ^ 1][(i * kThreads + threadIdx.x) * 2]) = stage[i];
-        }
+        if (t + 1 < ntiles) commit_tile(t + 1, buf ^ 1);
         __syncthreads();   // next buffer complete, current buffer free for tile t+2
     }
 
@@ -246,57 +438,41 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_ldsp(const double *__restri
         const long row = row0 + r;
         if (row < rows) {
             if (lane == 0) Ap[row] = s;
-            d += p_local[row] * s;   // same value in every lane
+            const int j = row0_global + (int)row;
+            double pl = v[j];
+            if constexpr (FUSED) pl = fma(beta, pl, seg_load(sv, j));
+            d += pl * s;   // same value in every lane
         }
     }
     if (lane == 0) red[w] = d;
     __syncthreads();
     if (threadIdx.x == 0) {
-        double s = red[0];
+        double tot = red[0];
 #pragma unroll
-        for (int i = 1; i < WAVES; ++i) s += red[i];
-        partials[blockIdx.x] = s;
+        for (int i = 1; i < WAVES; ++i) tot += red[i];
+        partials[blockIdx.x] = tot;
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// K2: one workgroup folds the per-workgroup partials in a fixed order.
-// ------------------------------------------------------------------------------------------------
-template <int NV>
-__global__ __launch_bounds__(256) void k_reduce_partials(const double *__restrict__ partials, int n,
-                                                          double *__restrict__ out, const int *__restrict__ done)
-{
-    if (done && *done) return;
-    __shared__ double lds[4];
-    for (int v = 0; v < NV; ++v) {
-        double s = 0.0;
-        for (int i = threadIdx.x; i < n; i += 256) s += partials[(long)i * NV + v];
-        s = block_sum<4>(s, lds);
-        if (threadIdx.x == 0) out[v] = s;
-    }
-}
-
-// gathered layout on every shard: [rank q][slot v], kSlots doubles per rank
-__device__ __forceinline__ double sum_ranks(const double *__restrict__ gathered, int slot, int nranks)
-{
-    double s = gathered[slot];
-    for (int q = 1; q < nranks; ++q) s += gathered[q * kSlots + slot];   // rank order, same on every shard
-    return s;
-}
-
-// ------------------------------------------------------------------------------------------------
-// K3: x += alpha p ; r -= alpha Ap ; partial r.r          (cg.cc:107-116)
+// K3: x += alpha p ; r -= alpha Ap ; r.r          (cg.cc:107-116)
+// r is this shard's slice inside the exchange segment; r.r lands in the segment's scalar slot.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_update_xr(int count, const double *__restrict__ p_local,
                                                     const double *__restrict__ Ap, double *__restrict__ x,
-                                                    double *__restrict__ r, const Scalars *__restrict__ sc, int parity,
-                                                    const double *__restrict__ gathered, int nranks,
-                                                    double *__restrict__ partials)
+                                                    SegView sv, Scalars *sc, int parity,
+                                                    const double *__restrict__ gathered, int ngathered, double *partials)
 {
     if (sc->done) return;
     __shared__ double lds[4];
+    __shared__ int s_flag;
+    double *r = sv.base + (long)sv.rank * sv.S;
     const double rsold = sc->rs[parity];
-    const double conj = sum_ranks(gathered, kSlotConj, nranks);                 // MPI_Allreduce, cg.cc:106
+    // p.Ap = sum of every K1 workgroup partial of every rank (cblas_ddot + MPI_Allreduce, cg.cc:105-106), folded
+    // in one fixed order by every workgroup of every rank: bit-identical everywhere.
+    double cs = 0.0;
+    for (int i = threadIdx.x; i < ngathered; i += 256) cs += gathered[i];
+    const double conj = block_sum<4>(cs, lds);
     const double alpha = rsold / fmax(conj, rsold * kNearZero);      // cg.cc:107
     const int i = blockIdx.x * 256 + threadIdx.x;
     double rr = 0.0;
@@ -307,58 +483,59 @@ __global__ __launch_bounds__(256) void k_update_xr(int count, const double *__re
         rr = rn * rn;                                                 // cg.cc:116
     }
     rr = block_sum<4>(rr, lds);
-    if (threadIdx.x == 0) partials[blockIdx.x] = rr;
+    grid_sum_last_arriver<4>(rr, partials, &sc->counter[1], r + sv.Sr + kSlotRr, lds, &s_flag);
+}
+
+// Loop ran out after k iterations: the tail of iteration k-1 that the next K1 would have done.
+__global__ void k_close_iteration(Scalars *sc, SegView sv, int k, double tol)
+{
+    if (blockIdx.x != 0 || threadIdx.x != 0 || sc->done) return;
+    const double rsnew = seg_sum_slot(sv, kSlotRr);                  // cg.cc:117 (k == 0: cg.cc:92)
+    if (k == 0) { sc->rs[0] = rsnew; sc->rs[1] = rsnew; return; }    // no iteration ran: only rsold exists
+    sc->rs[k & 1] = rsnew;                                           // cg.cc:132
+    if (sqrt(rsnew) < tol) { sc->k_final = k - 1; sc->done = 1; }    // cg.cc:120-121
 }
 
 // ------------------------------------------------------------------------------------------------
-// K4: convergence test, beta, p = r + beta p, rsold <- rsnew   (cg.cc:117-132)
+// K2, stand-alone form (setup / verification only): one workgroup folds partials in a fixed order.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_update_p(int count, const double *__restrict__ r, double *__restrict__ p_local,
-                                                   Scalars *__restrict__ sc, int parity, int k, double tol,
-                                                   const double *__restrict__ gathered, int nranks)
+template <int NV>
+__global__ __launch_bounds__(256) void k_reduce_partials(const double *__restrict__ partials, int n,
+                                                          double *__restrict__ out)
 {
-    if (sc->done) return;
-    const double rsold = sc->rs[parity];
-    const double rsnew = sum_ranks(gathered, kSlotRr, nranks);                // MPI_Allreduce, cg.cc:117
-    const bool first = (blockIdx.x == 0 && threadIdx.x == 0);
-    if (first) sc->rs[parity ^ 1] = rsnew;                           // becomes rsold of iteration k+1, cg.cc:132
-    if (sqrt(rsnew) < tol) {                                         // cg.cc:120-121: break before the p update
-        if (first) { sc->k_final = k; sc->done = 1; }
-        return;
+    __shared__ double lds[4];
+    for (int v = 0; v < NV; ++v) {
+        double s = 0.0;
+        for (int i = threadIdx.x; i < n; i += 256) s += partials[(long)i * NV + v];
+        s = block_sum<4>(s, lds);
+        if (threadIdx.x == 0) out[v] = s;
     }
-    const double beta = rsnew / rsold;                               // cg.cc:124
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i < count) p_local[i] = fma(beta, p_local[i], r[i]);         // cg.cc:127-129
 }
 
 // ------------------------------------------------------------------------------------------------
 // setup / verification kernels (outside the iteration loop)
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_init_residual(int count, const double *__restrict__ b,
-                                                        const double *__restrict__ Ap, double *__restrict__ r,
-                                                        double *__restrict__ p_local, double *__restrict__ partials)
+                                                        const double *__restrict__ Ap, SegView sv,
+                                                        double *__restrict__ partials)
 {
     __shared__ double lds[4];
+    double *r = sv.base + (long)sv.rank * sv.S;
     const int i = blockIdx.x * 256 + threadIdx.x;
     double rr = 0.0;
     if (i < count) {
         const double rv = b[i] - Ap[i];        // r_sub = b_sub - A_sub x, cg.cc:79-82
         r[i] = rv;
-        p_local[i] = rv;                       // p_sub = r_sub, cg.cc:85
-        rr = rv * rv;                          // rsold = r.p with p == r, cg.cc:91
+        rr = rv * rv;                          // rsold = r.p with p == r, cg.cc:85,91
     }
     rr = block_sum<4>(rr, lds);
     if (threadIdx.x == 0) partials[blockIdx.x] = rr;
 }
 
-__global__ void k_set_rsold(Scalars *sc, const double *__restrict__ gathered, int nranks)
+__global__ __launch_bounds__(256) void k_unpack_segments(SegView sv, double *__restrict__ v_full, long lda)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        sc->rs[0] = sum_ranks(gathered, kSlotRr, nranks);   // cg.cc:92
-        sc->rs[1] = sc->rs[0];
-        sc->done = 0;
-        sc->k_final = 0;
-    }
+    for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < lda; c += (long)gridDim.x * 256)
+        v_full[c] = (c < sv.n) ? seg_load(sv, (int)c) : 0.0;
 }
 
 __global__ __launch_bounds__(256) void k_debug_norms(int count, const double *__restrict__ Ax,
@@ -436,6 +613,24 @@ __global__ void k_loopback_gather(double *const *gathered_ptrs, const Scalars *c
 // ------------------------------------------------------------------------------------------------
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
+void seg_finalize(SegView *sv)
+{
+    sv->seg_gap = sv->S - sv->n_loc;
+    // Round-up magic for dividends c < 2^31 (Granlund-Montgomery): s = ceil(log2 d), m = floor(2^(31+s)/d) + 1
+    // fits 32 bits and floor(c/d) == (c*m) >> (31+s) == umulhi(c,m) >> (s-1) exactly.  d == 1 is flagged by
+    // div_shift == 32 (quotient = c); n_loc == 0 (N < P: every column belongs to the last rank) uses d = 2^31 - 1.
+    const unsigned d = sv->n_loc > 0 ? (unsigned)sv->n_loc : 0x7fffffffu;
+    if (d == 1) {
+        sv->div_magic = 0;
+        sv->div_shift = 32;
+        return;
+    }
+    unsigned s = 0;
+    while ((1ull << s) < d) ++s;
+    sv->div_magic = (unsigned)(((1ull << (31 + s)) / d) + 1);
+    sv->div_shift = s - 1;
+}
+
 GemvPlan plan_gemv(int variant, int rows, int ncols)
 {
     (void)ncols;
@@ -445,11 +640,14 @@ GemvPlan plan_gemv(int variant, int rows, int ncols)
         // default: column-split, as many rows per workgroup as still leaves >= 4 workgroups per CU
         pl.variant = 1;
         pl.nt = 1;
-        if (rows >= 8192) { pl.R = 8; pl.U = 2; }
-        else if (rows >= 2048) { pl.R = 4; pl.U = 4; }
+        // measured on MI355X at N=32768 (profiles/r01_k1_*): 8 rows per workgroup; two steps in flight per
+        // wave once the grid is large enough to fill the chip several times over, one step below that.
+        if (rows >= 16384) { pl.R = 8; pl.U = 2; }
+        else if (rows >= 2048) { pl.R = 8; pl.U = 1; }
+        else if (rows >= 512) { pl.R = 4; pl.U = 2; }
         else { pl.R = 2; pl.U = 4; }
     } else {
-        // explicit shape: variant*10000 + R*100 + U*10 + nt   (e.g. 10821, 20441, 11611)
+        // explicit shape: variant*10000 + R*100 + U*10 + 1   (e.g. 10821, 20441, 11611); the last digit is ignored
         pl.variant = variant / 10000;
         pl.R = (variant / 100) % 100;
         pl.U = (variant / 10) % 10;
@@ -462,31 +660,42 @@ GemvPlan plan_gemv(int variant, int rows, int ncols)
         pl.rows_per_wg = pl.R;
     }
     pl.grid = ceil_div(rows, pl.rows_per_wg);
+    if (pl.grid < 1) pl.grid = 1;   // a shard without rows still runs the iteration head and stores p
     return pl;
 }
 
-template <int R, int U, bool NT>
-static hipError_t launch_gemv_shape(const GemvPlan &pl, const double *A, long lda, int rows, const double *p_full,
-                                    const double *p_local, double *Ap, double *partials, const int *done, hipStream_t s)
+namespace {
+
+struct GemvArgs {
+    const double *A;
+    long lda;
+    int rows, row0;
+    const double *v;
+    double *p_new;
+    SegView sv;
+    double *Ap, *partials;
+    Scalars *sc;
+    int k;
+    double tol;
+};
+
+template <int R, int U, int MODE>
+hipError_t launch_shape(const GemvPlan &pl, const GemvArgs &g, hipStream_t s)
 {
     if (pl.variant == 2)
-        hipLaunchKernelGGL((k_gemv_ldsp<R, U, 4, NT>), dim3(pl.grid), dim3(256), 0, s, A, lda, rows, p_full, p_local, Ap,
-                           partials, done);
+        hipLaunchKernelGGL((k_gemv_ldsp<R, U, 4, MODE>), dim3(pl.grid), dim3(256), 0, s, g.A, g.lda, g.rows, g.row0, g.v,
+                           g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol);
     else
-        hipLaunchKernelGGL((k_gemv_colsplit<R, U, 4, NT>), dim3(pl.grid), dim3(256), 0, s, A, lda, rows, p_full, p_local,
-                           Ap, partials, done);
+        hipLaunchKernelGGL((k_gemv_colsplit<R, U, 4, MODE>), dim3(pl.grid), dim3(256), 0, s, g.A, g.lda, g.rows, g.row0,
+                           g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol);
     return hipGetLastError();
 }
 
-hipError_t launch_gemv(const GemvPlan &pl, const double *A, long lda, int rows, const double *p_full,
-                       const double *p_local, double *Ap, double *partials, const int *done, hipStream_t s)
+template <int MODE>
+hipError_t dispatch_gemv(const GemvPlan &pl, const GemvArgs &g, hipStream_t s)
 {
-    if (rows <= 0) return hipSuccess;
-#define CGX_SHAPE(r, u)                                                                                      \
-    if (pl.R == r && pl.U == u) {                                                                            \
-        return pl.nt ? launch_gemv_shape<r, u, true>(pl, A, lda, rows, p_full, p_local, Ap, partials, done, s) \
-                     : launch_gemv_shape<r, u, false>(pl, A, lda, rows, p_full, p_local, Ap, partials, done, s); \
-    }
+#define CGX_SHAPE(r, u) \
+    if (pl.R == r && pl.U == u) return launch_shape<r, u, MODE>(pl, g, s);
     CGX_SHAPE(8, 2)
     CGX_SHAPE(8, 1)
     CGX_SHAPE(4, 4)
@@ -499,48 +708,63 @@ hipError_t launch_gemv(const GemvPlan &pl, const double *A, long lda, int rows, 
     return hipErrorInvalidValue;
 }
 
-hipError_t launch_reduce_partials(const double *partials, int n, double *out, const int *done, hipStream_t s)
+}  // namespace
+
+hipError_t launch_gemv_plain(const GemvPlan &pl, const double *A, long lda, int rows, const double *v_full,
+                             const double *v_local, double *Ap, double *partials, Scalars *sc, hipStream_t s)
 {
-    hipLaunchKernelGGL((k_reduce_partials<1>), dim3(1), dim3(256), 0, s, partials, n, out, done);
+    GemvArgs g{A, lda, rows, (int)(v_local - v_full), v_full, nullptr, SegView{}, Ap, partials, sc, 0, 0.0};
+    return dispatch_gemv<kPlain>(pl, g, s);
+}
+
+hipError_t launch_gemv_fused(const GemvPlan &pl, const double *A, long lda, int rows, int row0, const double *p_old,
+                             double *p_new, SegView seg, double *Ap, double *partials, Scalars *sc, int k, double tol,
+                             hipStream_t s)
+{
+    GemvArgs g{A, lda, rows, row0, p_old, p_new, seg, Ap, partials, sc, k, tol};
+    return seg.nranks == 1 ? dispatch_gemv<kFusedSingle>(pl, g, s) : dispatch_gemv<kFusedMulti>(pl, g, s);
+}
+
+int update_xr_grid(int count) { return count > 0 ? ceil_div(count, 256) : 1; }
+
+hipError_t launch_update_xr(int count, const double *p_local, const double *Ap, double *x, SegView seg, Scalars *sc,
+                            int parity, const double *gathered, int ngathered, double *partials, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_update_xr, dim3(update_xr_grid(count)), dim3(256), 0, s, count, p_local, Ap, x, seg, sc, parity,
+                       gathered, ngathered, partials);
+    return hipGetLastError();
+}
+
+hipError_t launch_close_iteration(Scalars *sc, SegView seg, int k, double tol, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_close_iteration, dim3(1), dim3(64), 0, s, sc, seg, k, tol);
+    return hipGetLastError();
+}
+
+hipError_t launch_reduce_partials(const double *partials, int n, double *out, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_reduce_partials<1>), dim3(1), dim3(256), 0, s, partials, n, out);
     return hipGetLastError();
 }
 
 hipError_t launch_reduce_partials3(const double *partials, int n, double *out3, hipStream_t s)
 {
-    hipLaunchKernelGGL((k_reduce_partials<3>), dim3(1), dim3(256), 0, s, partials, n, out3, (const int *)nullptr);
+    hipLaunchKernelGGL((k_reduce_partials<3>), dim3(1), dim3(256), 0, s, partials, n, out3);
     return hipGetLastError();
 }
 
-int update_xr_grid(int count) { return count > 0 ? ceil_div(count, 256) : 1; }
-
-hipError_t launch_update_xr(int count, const double *p_local, const double *Ap, double *x, double *r,
-                            const Scalars *sc, int parity, const double *gathered, int nranks, double *partials,
-                            hipStream_t s)
+hipError_t launch_init_residual(int count, const double *b, const double *Ap, SegView seg, double *partials,
+                                hipStream_t s)
 {
-    hipLaunchKernelGGL(k_update_xr, dim3(update_xr_grid(count)), dim3(256), 0, s, count, p_local, Ap, x, r, sc, parity,
-                       gathered, nranks, partials);
+    hipLaunchKernelGGL(k_init_residual, dim3(update_xr_grid(count)), dim3(256), 0, s, count, b, Ap, seg, partials);
     return hipGetLastError();
 }
 
-hipError_t launch_update_p(int count, const double *r, double *p_local, Scalars *sc, int parity, int k, double tol,
-                           const double *gathered, int nranks, hipStream_t s)
+hipError_t launch_unpack_segments(SegView seg, double *v_full, long lda, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_update_p, dim3(update_xr_grid(count)), dim3(256), 0, s, count, r, p_local, sc, parity, k, tol,
-                       gathered, nranks);
-    return hipGetLastError();
-}
-
-hipError_t launch_init_residual(int count, const double *b, const double *Ap, double *r, double *p_local,
-                                double *partials, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_init_residual, dim3(update_xr_grid(count)), dim3(256), 0, s, count, b, Ap, r, p_local,
-                       partials);
-    return hipGetLastError();
-}
-
-hipError_t launch_set_rsold(Scalars *sc, const double *gathered, int nranks, hipStream_t s)
-{
-    hipLaunchKernelGGL(k_set_rsold, dim3(1), dim3(64), 0, s, sc, gathered, nranks);
+    int grid = ceil_div(lda, 256);
+    if (grid > 1024) grid = 1024;
+    hipLaunchKernelGGL(k_unpack_segments, dim3(grid), dim3(256), 0, s, seg, v_full, lda);
     return hipGetLastError();
 }
 

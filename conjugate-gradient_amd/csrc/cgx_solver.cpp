@@ -7,9 +7,10 @@
 //     enqueues kernels and polls one int every `check_every` iterations, so the stream never drains;
 //   * after convergence every kernel of the remaining enqueued iterations exits at its first
 //     instruction, which reproduces the reference's `break` (cg.cc:120-121) exactly;
-//   * MPI_Allreduce of one double  -> all-gather of kSlots doubles per rank + rank-ordered sum inside
-//     the consuming kernel (bit-identical on all ranks); MPI_Allgatherv of p -> in-place ncclAllGather
-//     (or grouped ncclBroadcast when N % P != 0) straight into the replicated p that K1 reads.
+//   * one iteration = two kernels (K1 fused GEMV, K3 x/r update) and two exchanges:
+//     MPI_Allreduce(p.Ap) -> all-gather of kSlots doubles per rank + rank-ordered sum inside K3;
+//     MPI_Allreduce(r.r) + MPI_Allgatherv(p) -> ONE in-place all-gather of equal segments
+//     [r slice | r.r partial]; every rank then forms p = r + beta p itself inside K1 (cgx_kernels.hip).
 #include "../../include/cgx.h"
 
 #include <hip/hip_runtime.h>
@@ -50,13 +51,16 @@ struct Shard {
     double *A = nullptr;         // rows x lda, row-major, pad columns zero
     double *b = nullptr;         // rows
     double *x = nullptr;         // rows
-    double *r = nullptr;         // rows
     double *Ap = nullptr;        // rows
-    double *p_full = nullptr;    // lda doubles: the replicated p (cg.cc:57); this shard's slice is p_full + row0
-    double *partials = nullptr;  // per-workgroup partial sums
+    double *p[2] = {nullptr, nullptr};   // lda doubles each: the replicated p (cg.cc:57), ping-pong over iterations
+    double *rg = nullptr;        // nranks * S doubles: exchanged segments [r slice | scalars] (cgx::SegView)
+    double *partials = nullptr;  // scratch: per-workgroup partial sums of K3 and of the setup kernels
+    double *k1_part = nullptr;   // npart doubles: K1's per-workgroup p.Ap partials (send buffer of exchange 1)
+    double *k1_gath = nullptr;   // nranks * npart doubles: every rank's K1 partials (SELF: == k1_part)
     Scalars *sc = nullptr;
-    double *gathered = nullptr;  // kMaxRanks * kSlots doubles
+    double *gathered = nullptr;  // kMaxRanks * kSlots doubles (DEBUG scalars of all ranks)
     cgx::GemvPlan plan{};
+    cgx::SegView seg{};
     int npartials = 0;
 };
 
@@ -79,7 +83,8 @@ struct cgx_ctx {
     // RCCL
     const cgx::RcclApi *rccl = nullptr;
     ncclComm_t comm = nullptr;
-    bool even_partition = true;
+    int seg_S = 0, seg_Sr = 0;   // exchange segment geometry (equal for all ranks)
+    int npart = 0;               // K1 partials per rank in exchange 1 (max grid over ranks)
 
     // loopback pointer tables (device)
     double **d_gathered_ptrs = nullptr;
@@ -99,6 +104,7 @@ struct cgx_ctx {
     size_t ev_used = 0;
     double gemv_ms_sum = 0, gemv_ms_min = 0;
     long long gemv_launches = 0;
+    long long gemv_seq = 0;
 
     std::string err;
 };
@@ -155,10 +161,13 @@ void free_shard(Shard &s)
     (void)hipFree(s.A);
     (void)hipFree(s.b);
     (void)hipFree(s.x);
-    (void)hipFree(s.r);
     (void)hipFree(s.Ap);
-    (void)hipFree(s.p_full);
+    (void)hipFree(s.p[0]);
+    (void)hipFree(s.p[1]);
+    (void)hipFree(s.rg);
     (void)hipFree(s.partials);
+    (void)hipFree(s.k1_part);
+    if (s.k1_gath != s.k1_part) (void)hipFree(s.k1_gath);
     (void)hipFree(s.sc);
     (void)hipFree(s.gathered);
     s = Shard{};
@@ -182,7 +191,7 @@ long default_lda(const cgx_ctx *ctx, int n)
     int pad = ctx->cfg.lda_pad;
     if (pad < 0) {
         const char *e = getenv("CGX_LDA_PAD");
-        pad = e ? atoi(e) : 0;
+        pad = e ? atoi(e) : 16;   // +128 B per row: de-aliases the HBM channels when N*8 is a power of two
     }
     if (pad > 0) lda += (pad + 1) / 2 * 2;
     return lda;
@@ -200,15 +209,20 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
     ctx->start_rows.assign(ctx->nranks, 0);
     ctx->num_rows.assign(ctx->nranks, 0);
     partition_rows(n, ctx->nranks, ctx->start_rows.data(), ctx->num_rows.data());
-    ctx->even_partition = true;
-    for (int q = 0; q < ctx->nranks; ++q)
-        if (ctx->num_rows[q] != ctx->num_rows[0]) ctx->even_partition = false;
+    int max_rows = 0;
+    for (int q = 0; q < ctx->nranks; ++q) max_rows = std::max(max_rows, ctx->num_rows[q]);
+    ctx->seg_Sr = std::max((max_rows + 1) / 2 * 2, 2);   // r part, padded to an even count
+    if (ctx->nranks == 1) ctx->seg_Sr = (int)ctx->lda;   // one shard: r is contiguous and zero padded like p (16-B loads)
+    ctx->seg_S = ctx->seg_Sr + cgx::kSlots;
 
     int variant = ctx->cfg.gemv_variant;
     if (variant <= 0) {
         const char *e = getenv("CGX_GEMV_VARIANT");
         if (e) variant = atoi(e);
     }
+    ctx->npart = 1;
+    for (int q = 0; q < ctx->nranks; ++q)
+        ctx->npart = std::max(ctx->npart, cgx::plan_gemv(variant, ctx->num_rows[q], (int)ctx->lda).grid);
     const int nlocal = (ctx->cfg.comm_mode == CGX_COMM_LOOPBACK) ? ctx->nranks : 1;
     ctx->shards.resize(nlocal);
     for (int i = 0; i < nlocal; ++i) {
@@ -222,13 +236,28 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
         HIP_TRY(ctx, hipMalloc(&s.A, rows_alloc * (size_t)ctx->lda * sizeof(double)));
         HIP_TRY(ctx, hipMalloc(&s.b, rows_alloc * sizeof(double)));
         HIP_TRY(ctx, hipMalloc(&s.x, rows_alloc * sizeof(double)));
-        HIP_TRY(ctx, hipMalloc(&s.r, rows_alloc * sizeof(double)));
         HIP_TRY(ctx, hipMalloc(&s.Ap, rows_alloc * sizeof(double)));
-        HIP_TRY(ctx, hipMalloc(&s.p_full, (size_t)ctx->lda * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&s.p[0], (size_t)ctx->lda * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&s.p[1], (size_t)ctx->lda * sizeof(double)));
+        const size_t rg_bytes = (size_t)ctx->nranks * ctx->seg_S * sizeof(double);
+        HIP_TRY(ctx, hipMalloc(&s.rg, rg_bytes));
+        s.seg = cgx::SegView{s.rg, ctx->seg_S, ctx->seg_Sr, n / ctx->nranks, ctx->nranks, n, s.rank, 0, 0, 0};
+        cgx::seg_finalize(&s.seg);
         HIP_TRY(ctx, hipMalloc(&s.partials, (size_t)s.npartials * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&s.k1_part, (size_t)ctx->npart * sizeof(double)));
+        HIP_TRY(ctx, hipMemsetAsync(s.k1_part, 0, (size_t)ctx->npart * sizeof(double), ctx->stream));
+        if (ctx->cfg.comm_mode == CGX_COMM_SELF) {
+            s.k1_gath = s.k1_part;
+        } else {
+            HIP_TRY(ctx, hipMalloc(&s.k1_gath, (size_t)ctx->nranks * ctx->npart * sizeof(double)));
+            HIP_TRY(ctx, hipMemsetAsync(s.k1_gath, 0, (size_t)ctx->nranks * ctx->npart * sizeof(double), ctx->stream));
+        }
         HIP_TRY(ctx, hipMalloc(&s.sc, sizeof(Scalars)));
         HIP_TRY(ctx, hipMalloc(&s.gathered, (size_t)cgx::kMaxRanks * cgx::kSlots * sizeof(double)));
-        HIP_TRY(ctx, hipMemsetAsync(s.p_full, 0, (size_t)ctx->lda * sizeof(double), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(s.p[0], 0, (size_t)ctx->lda * sizeof(double), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(s.p[1], 0, (size_t)ctx->lda * sizeof(double), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(s.rg, 0, rg_bytes, ctx->stream));
+        if (s.rows <= 0) HIP_TRY(ctx, hipMemsetAsync(s.A, 0, (size_t)ctx->lda * sizeof(double), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(s.partials, 0, (size_t)s.npartials * sizeof(double), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(s.sc, 0, sizeof(Scalars), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(s.gathered, 0, (size_t)cgx::kMaxRanks * cgx::kSlots * sizeof(double), ctx->stream));
@@ -253,11 +282,6 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
 
 // Scalars: every shard contributes sc->local[kSlots]; afterwards every shard's gathered[] holds all of them.
 // Replaces MPI_Allreduce (cg.cc:92,106,117).  In SELF mode the consumers read sc->local directly.
-const double *gathered_ptr(const cgx_ctx *ctx, const Shard &s)
-{
-    return (ctx->cfg.comm_mode == CGX_COMM_SELF) ? s.sc->local : s.gathered;
-}
-
 cgx_status gather_scalars(cgx_ctx *ctx)
 {
     switch (ctx->cfg.comm_mode) {
@@ -274,41 +298,47 @@ cgx_status gather_scalars(cgx_ctx *ctx)
     }
 }
 
-// Replicated vector: every shard's slice [row0,row0+rows) of its own p_full is current; afterwards all of
-// p_full is.  Replaces MPI_Allgatherv (cg.cc:87-88,135-136) and, for x, MPI_Gatherv (cg.cc:140-142).
-cgx_status gather_p(cgx_ctx *ctx)
+// Exchange 1: every rank's K1 partials (npart doubles, zero beyond its own grid) to every rank.  Replaces the
+// MPI_Allreduce of p.Ap (cg.cc:106): K3 folds all nranks*npart values in one fixed order on every rank.
+cgx_status gather_k1_partials(cgx_ctx *ctx)
 {
+    const size_t np = (size_t)ctx->npart;
     switch (ctx->cfg.comm_mode) {
     case CGX_COMM_SELF:
         return CGX_OK;
     case CGX_COMM_LOOPBACK:
         for (auto &dst : ctx->shards)
             for (auto &src : ctx->shards)
-                if (dst.rank != src.rank && src.rows > 0)
-                    HIP_TRY(ctx, hipMemcpyAsync(dst.p_full + src.row0, src.p_full + src.row0,
-                                                (size_t)src.rows * sizeof(double), hipMemcpyDeviceToDevice,
-                                                ctx->stream));
+                HIP_TRY(ctx, hipMemcpyAsync(dst.k1_gath + src.rank * np, src.k1_part, np * sizeof(double),
+                                            hipMemcpyDeviceToDevice, ctx->stream));
         return CGX_OK;
     default: {
         Shard &s = ctx->shards[0];
-        if (ctx->even_partition) {
-            NCCL_TRY(ctx, ctx->rccl->AllGather(s.p_full + s.row0, s.p_full, (size_t)s.rows, ncclDouble, ctx->comm,
-                                               ctx->stream));
-        } else {
-            // N % P != 0: the last rank owns more rows (cg.cc:265-266).  One fused group of in-place broadcasts.
-            NCCL_TRY(ctx, ctx->rccl->GroupStart());
-            for (int q = 0; q < ctx->nranks; ++q) {
-                if (ctx->num_rows[q] <= 0) continue;
-                double *seg = s.p_full + ctx->start_rows[q];
-                ncclResult_t r = ctx->rccl->Broadcast(seg, seg, (size_t)ctx->num_rows[q], ncclDouble, q, ctx->comm,
-                                                      ctx->stream);
-                if (r != ncclSuccess) {
-                    (void)ctx->rccl->GroupEnd();
-                    return fail(ctx, CGX_ERR_RCCL, std::string("ncclBroadcast: ") + ctx->rccl->GetErrorString(r));
-                }
-            }
-            NCCL_TRY(ctx, ctx->rccl->GroupEnd());
-        }
+        NCCL_TRY(ctx, ctx->rccl->AllGather(s.k1_part, s.k1_gath, np, ncclDouble, ctx->comm, ctx->stream));
+        return CGX_OK;
+    }
+    }
+}
+
+// Exchange segments: every shard's own segment [r slice | scalars] inside its rg is current; afterwards all
+// P segments are.  Replaces MPI_Allgatherv (cg.cc:87-88,135-136) AND the MPI_Allreduce of r.r (cg.cc:92,117)
+// in one message; segments have the same size on every rank, so N % P != 0 needs no special case.
+cgx_status gather_segments(cgx_ctx *ctx)
+{
+    const size_t S = (size_t)ctx->seg_S;
+    switch (ctx->cfg.comm_mode) {
+    case CGX_COMM_SELF:
+        return CGX_OK;
+    case CGX_COMM_LOOPBACK:
+        for (auto &dst : ctx->shards)
+            for (auto &src : ctx->shards)
+                if (dst.rank != src.rank)
+                    HIP_TRY(ctx, hipMemcpyAsync(dst.rg + src.rank * S, src.rg + src.rank * S, S * sizeof(double),
+                                                hipMemcpyDeviceToDevice, ctx->stream));
+        return CGX_OK;
+    default: {
+        Shard &s = ctx->shards[0];
+        NCCL_TRY(ctx, ctx->rccl->AllGather(s.rg + s.rank * S, s.rg, S, ncclDouble, ctx->comm, ctx->stream));
         return CGX_OK;
     }
     }
@@ -326,16 +356,27 @@ cgx_status take_event(cgx_ctx *ctx, hipEvent_t *out)
     return CGX_OK;
 }
 
-cgx_status run_gemv(cgx_ctx *ctx, Shard &s, const int *done, bool timed)
+// K1, plain form (vector given): initial residual, DEBUG verification, probes.
+cgx_status run_gemv_plain(cgx_ctx *ctx, Shard &s, const double *v_full)
 {
+    HIP_TRY(ctx, cgx::launch_gemv_plain(s.plan, s.A, ctx->lda, s.rows, v_full, v_full + s.row0, s.Ap, s.k1_part, s.sc,
+                                        ctx->stream));
+    return CGX_OK;
+}
+
+// K1, fused form of iteration k; every `profile_gemv`-th launch is bracketed with HIP events.
+cgx_status run_gemv_fused(cgx_ctx *ctx, Shard &s, int k)
+{
+    const int every = ctx->cfg.profile_gemv;
+    const bool timed = every > 0 && (ctx->gemv_seq++ % every) == 0;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timed) {
         CGX_TRY(take_event(ctx, &e0));
         CGX_TRY(take_event(ctx, &e1));
         HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
     }
-    HIP_TRY(ctx, cgx::launch_gemv(s.plan, s.A, ctx->lda, s.rows, s.p_full, s.p_full + s.row0, s.Ap, s.partials, done,
-                                  ctx->stream));
+    HIP_TRY(ctx, cgx::launch_gemv_fused(s.plan, s.A, ctx->lda, s.rows, s.row0, s.p[k & 1], s.p[(k + 1) & 1], s.seg, s.Ap,
+                                        s.k1_part, s.sc, k, ctx->tol, ctx->stream));
     if (timed) HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
     return CGX_OK;
 }
@@ -354,28 +395,17 @@ cgx_status harvest_gemv_events(cgx_ctx *ctx)
     return CGX_OK;
 }
 
-// ---- one body of the loop cg.cc:96-137 -------------------------------------------------------------
+// ---- one body of the loop cg.cc:96-137: two kernels, two exchanges ------------------------------------
 cgx_status enqueue_iteration(cgx_ctx *ctx, int k)
 {
-    const int par = k & 1;
-    const bool timed = ctx->cfg.profile_gemv != 0;
     hipStream_t st = ctx->stream;
-    for (auto &s : ctx->shards) CGX_TRY(run_gemv(ctx, s, &s.sc->done, timed));                       // cg.cc:100-102
+    // tail of iteration k-1 (cg.cc:117-132) + GEMV and p.Ap of iteration k (cg.cc:100-105)
+    for (auto &s : ctx->shards) CGX_TRY(run_gemv_fused(ctx, s, k));
+    CGX_TRY(gather_k1_partials(ctx));                                                                // cg.cc:106
     for (auto &s : ctx->shards)
-        HIP_TRY(ctx, cgx::launch_reduce_partials(s.partials, s.plan.grid, &s.sc->local[cgx::kSlotConj], &s.sc->done,
-                                                 st));                                               // cg.cc:105
-    CGX_TRY(gather_scalars(ctx));                                                                    // cg.cc:106
-    for (auto &s : ctx->shards)
-        HIP_TRY(ctx, cgx::launch_update_xr(s.rows, s.p_full + s.row0, s.Ap, s.x, s.r, s.sc, par, gathered_ptr(ctx, s),
-                                           ctx->nranks, s.partials, st));                            // cg.cc:107-116
-    for (auto &s : ctx->shards)
-        HIP_TRY(ctx, cgx::launch_reduce_partials(s.partials, cgx::update_xr_grid(s.rows), &s.sc->local[cgx::kSlotRr],
-                                                 &s.sc->done, st));
-    CGX_TRY(gather_scalars(ctx));                                                                    // cg.cc:117
-    for (auto &s : ctx->shards)
-        HIP_TRY(ctx, cgx::launch_update_p(s.rows, s.r, s.p_full + s.row0, s.sc, par, k, ctx->tol, gathered_ptr(ctx, s),
-                                          ctx->nranks, st));                                         // cg.cc:120-132
-    CGX_TRY(gather_p(ctx));                                                                          // cg.cc:135-136
+        HIP_TRY(ctx, cgx::launch_update_xr(s.rows, s.p[(k + 1) & 1] + s.row0, s.Ap, s.x, s.seg, s.sc, k & 1, s.k1_gath,
+                                           ctx->nranks * ctx->npart, s.partials, st));               // cg.cc:105-116
+    CGX_TRY(gather_segments(ctx));                                                                   // cg.cc:117,135-136
     return CGX_OK;
 }
 
@@ -734,23 +764,30 @@ cgx_status cgx_solve_begin(cgx_ctx *ctx, const double *x0)
     ctx->ev_used = 0;
     ctx->gemv_ms_sum = ctx->gemv_ms_min = 0;
     ctx->gemv_launches = 0;
+    ctx->gemv_seq = 0;
     hipStream_t st = ctx->stream;
     const int n = ctx->n;
+    const size_t vec_bytes = (size_t)ctx->lda * sizeof(double);
     for (auto &s : ctx->shards) {
+        HIP_TRY(ctx, hipMemsetAsync(s.sc, 0, sizeof(Scalars), st));
+        HIP_TRY(ctx, hipMemsetAsync(s.rg, 0, (size_t)ctx->nranks * ctx->seg_S * sizeof(double), st));
         // x (initial guess) replicated for the first GEMV, x_sub = x[rows]  (cg.cc:72, 80)
-        HIP_TRY(ctx, hipMemcpyAsync(s.p_full, x0, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+        HIP_TRY(ctx, hipMemcpyAsync(s.p[0], x0, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
         if (s.rows > 0)
-            HIP_TRY(ctx, hipMemcpyAsync(s.x, s.p_full + s.row0, (size_t)s.rows * sizeof(double), hipMemcpyDeviceToDevice, st));
+            HIP_TRY(ctx, hipMemcpyAsync(s.x, s.p[0] + s.row0, (size_t)s.rows * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
-    for (auto &s : ctx->shards) CGX_TRY(run_gemv(ctx, s, nullptr, false));                           // cg.cc:79-81
+    for (auto &s : ctx->shards) CGX_TRY(run_gemv_plain(ctx, s, s.p[0]));                             // cg.cc:79-81
     for (auto &s : ctx->shards)
-        HIP_TRY(ctx, cgx::launch_init_residual(s.rows, s.b, s.Ap, s.r, s.p_full + s.row0, s.partials, st));   // cg.cc:82-85
+        HIP_TRY(ctx, cgx::launch_init_residual(s.rows, s.b, s.Ap, s.seg, s.partials, st));           // cg.cc:82
     for (auto &s : ctx->shards)
-        HIP_TRY(ctx, cgx::launch_reduce_partials(s.partials, cgx::update_xr_grid(s.rows), &s.sc->local[cgx::kSlotRr],
-                                                 nullptr, st));                                      // cg.cc:91
-    CGX_TRY(gather_scalars(ctx));                                                                    // cg.cc:92
-    for (auto &s : ctx->shards) HIP_TRY(ctx, cgx::launch_set_rsold(s.sc, gathered_ptr(ctx, s), ctx->nranks, st));
-    CGX_TRY(gather_p(ctx));                                                                          // cg.cc:87-88
+        HIP_TRY(ctx, cgx::launch_reduce_partials(s.partials, cgx::update_xr_grid(s.rows),
+                                                 s.rg + (size_t)s.rank * ctx->seg_S + ctx->seg_Sr + cgx::kSlotRr, st));   // cg.cc:91
+    for (auto &s : ctx->shards) {
+        // p_old of iteration 0 is 0, so K1(0) forms p = r + 0*0 = r  (p_sub = r_sub, cg.cc:85)
+        HIP_TRY(ctx, hipMemsetAsync(s.p[0], 0, vec_bytes, st));
+        HIP_TRY(ctx, hipMemsetAsync(s.p[1], 0, vec_bytes, st));
+    }
+    CGX_TRY(gather_segments(ctx));                                                                   // cg.cc:87-88,92
     ctx->in_solve = true;
     return CGX_OK;
 }
@@ -798,16 +835,21 @@ cgx_status cgx_solve_end(cgx_ctx *ctx, double *x, cgx_result *res)
     if (!ctx || !ctx->in_solve) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_solve_end outside begin");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    // The convergence test of the last enqueued iteration is normally done by the NEXT K1; when the loop
+    // ran out there is none, so close it here (cg.cc:117-121,132).
+    for (auto &s : ctx->shards) HIP_TRY(ctx, cgx::launch_close_iteration(s.sc, s.seg, ctx->k, ctx->tol, st));
     CGX_TRY(read_flags_sync(ctx));
     const int k_exit = ctx->done ? ctx->k_final : ctx->k;
 
-    // Gather x (MPI_Gatherv, cg.cc:140-142) into the replicated vector, then the DEBUG verification
+    // Gather x (MPI_Gatherv, cg.cc:140-142) through the exchange segments, then the DEBUG verification
     // (cg.cc:144-151) with the same K1, distributed over the shards instead of rank 0 alone.
     for (auto &s : ctx->shards)
         if (s.rows > 0)
-            HIP_TRY(ctx, hipMemcpyAsync(s.p_full + s.row0, s.x, (size_t)s.rows * sizeof(double), hipMemcpyDeviceToDevice, st));
-    CGX_TRY(gather_p(ctx));
-    for (auto &s : ctx->shards) CGX_TRY(run_gemv(ctx, s, nullptr, false));
+            HIP_TRY(ctx, hipMemcpyAsync(s.rg + (size_t)s.rank * ctx->seg_S, s.x, (size_t)s.rows * sizeof(double),
+                                        hipMemcpyDeviceToDevice, st));
+    CGX_TRY(gather_segments(ctx));
+    for (auto &s : ctx->shards) HIP_TRY(ctx, cgx::launch_unpack_segments(s.seg, s.p[0], ctx->lda, st));
+    for (auto &s : ctx->shards) CGX_TRY(run_gemv_plain(ctx, s, s.p[0]));
     for (auto &s : ctx->shards) HIP_TRY(ctx, cgx::launch_debug_norms(s.rows, s.Ap, s.b, s.x, s.partials, st));
     for (auto &s : ctx->shards)
         HIP_TRY(ctx, cgx::launch_reduce_partials3(s.partials, cgx::update_xr_grid(s.rows), s.sc->local, st));
@@ -819,7 +861,7 @@ cgx_status cgx_solve_end(cgx_ctx *ctx, double *x, cgx_result *res)
     HIP_TRY(ctx, hipMemcpyAsync(&hs, s0.sc, sizeof hs, hipMemcpyDeviceToHost, st));
     if (ctx->cfg.comm_mode != CGX_COMM_SELF)
         HIP_TRY(ctx, hipMemcpyAsync(hg.data(), s0.gathered, hg.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (x) HIP_TRY(ctx, hipMemcpyAsync(x, s0.p_full, (size_t)ctx->n * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (x) HIP_TRY(ctx, hipMemcpyAsync(x, s0.p[0], (size_t)ctx->n * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (ctx->cfg.comm_mode == CGX_COMM_SELF)
         for (int v = 0; v < cgx::kSlots; ++v) hg[v] = hs.local[v];
@@ -865,9 +907,10 @@ cgx_status cgx_probe_gemv(cgx_ctx *ctx, const double *p, double *y, double *pAp)
     hipStream_t st = ctx->stream;
     double total = 0.0;
     for (auto &s : ctx->shards) {
-        HIP_TRY(ctx, hipMemcpyAsync(s.p_full, p, (size_t)ctx->n * sizeof(double), hipMemcpyHostToDevice, st));
-        CGX_TRY(run_gemv(ctx, s, nullptr, false));
-        HIP_TRY(ctx, cgx::launch_reduce_partials(s.partials, s.plan.grid, &s.sc->local[cgx::kSlotConj], nullptr, st));
+        HIP_TRY(ctx, hipMemsetAsync(s.sc, 0, sizeof(Scalars), st));
+        HIP_TRY(ctx, hipMemcpyAsync(s.p[0], p, (size_t)ctx->n * sizeof(double), hipMemcpyHostToDevice, st));
+        CGX_TRY(run_gemv_plain(ctx, s, s.p[0]));
+        HIP_TRY(ctx, cgx::launch_reduce_partials(s.k1_part, s.plan.grid, &s.sc->local[cgx::kSlotConj], st));
         double part = 0.0;
         if (s.rows > 0)
             HIP_TRY(ctx, hipMemcpyAsync(y + s.row0, s.Ap, (size_t)s.rows * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -875,8 +918,31 @@ cgx_status cgx_probe_gemv(cgx_ctx *ctx, const double *p, double *y, double *pAp)
         HIP_TRY(ctx, hipStreamSynchronize(st));
         total += part;
     }
-    ctx->ev_used = 0;
     if (pAp) *pAp = total;
+    return CGX_OK;
+}
+
+cgx_status cgx_probe_time_gemv(cgx_ctx *ctx, int reps, double *ms_per_launch)
+{
+    if (!ctx || reps <= 0 || !ms_per_launch) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_probe_time_gemv: bad argument");
+    if (!ctx->have_matrix) return fail(ctx, CGX_ERR_BAD_ARG, "no matrix");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    for (auto &s : ctx->shards) HIP_TRY(ctx, hipMemsetAsync(s.sc, 0, sizeof(Scalars), st));
+    for (auto &s : ctx->shards) CGX_TRY(run_gemv_plain(ctx, s, s.p[0]));   // warm
+    HIP_TRY(ctx, hipEventRecord(e0, st));
+    for (int i = 0; i < reps; ++i)
+        for (auto &s : ctx->shards) CGX_TRY(run_gemv_plain(ctx, s, s.p[0]));
+    HIP_TRY(ctx, hipEventRecord(e1, st));
+    HIP_TRY(ctx, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_launch = (double)ms / reps / (double)ctx->shards.size();
     return CGX_OK;
 }
 
@@ -886,41 +952,56 @@ cgx_status cgx_probe_vector_ops(cgx_ctx *ctx, int n, double alpha, double beta, 
     if (!ctx || n <= 0 || !x || !r || !p || !Ap) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_probe_vector_ops: bad argument");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    double *dx = nullptr, *dr = nullptr, *dp = nullptr, *dAp = nullptr, *dpart = nullptr;
-    Scalars *dsc = nullptr;
-    const size_t bytes = (size_t)n * sizeof(double);
+    // A single-shard problem of length n around the PRODUCTION kernels: K3 for x/r/r.r, then the fused K1 of
+    // the next iteration (on a 1 x n zero matrix) for p = r + beta p.
+    const long lda = ((long)n + 15) / 16 * 16;
+    const int Sr = (int)lda, S = Sr + cgx::kSlots;   // single shard: r zero padded up to lda
+    const size_t bytes = (size_t)n * sizeof(double), vbytes = (size_t)lda * sizeof(double);
     const int grid = cgx::update_xr_grid(n);
+    double *dx = nullptr, *dAp = nullptr, *dp0 = nullptr, *dp1 = nullptr, *dseg = nullptr, *dpart = nullptr, *dA = nullptr,
+           *dAp1 = nullptr;
+    Scalars *dsc = nullptr;
     HIP_TRY(ctx, hipMalloc(&dx, bytes));
-    HIP_TRY(ctx, hipMalloc(&dr, bytes));
-    HIP_TRY(ctx, hipMalloc(&dp, bytes));
     HIP_TRY(ctx, hipMalloc(&dAp, bytes));
-    HIP_TRY(ctx, hipMalloc(&dpart, (size_t)grid * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc(&dp0, vbytes));
+    HIP_TRY(ctx, hipMalloc(&dp1, vbytes));
+    HIP_TRY(ctx, hipMalloc(&dseg, (size_t)S * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc(&dpart, (size_t)(grid + 8) * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc(&dA, vbytes));
+    HIP_TRY(ctx, hipMalloc(&dAp1, 8 * sizeof(double)));
     HIP_TRY(ctx, hipMalloc(&dsc, sizeof(Scalars)));
-    // Force the wanted alpha and beta through the production kernels: with rsold = alpha and conj = 1,
-    // K3 computes alpha / max(1, alpha*1e-14) = alpha; with rsnew = beta*alpha, K4 computes beta.
+    cgx::SegView sv{dseg, S, Sr, n, 1, n, 0, 0, 0, 0};
+    cgx::seg_finalize(&sv);
+    // Force the wanted alpha: with rsold = alpha and conj = 1, K3 computes alpha / max(1, alpha*1e-14) = alpha.
     Scalars hs{};
     hs.rs[0] = alpha;
     hs.local[cgx::kSlotConj] = 1.0;
-    hs.local[cgx::kSlotRr] = beta * alpha;
+    HIP_TRY(ctx, hipMemsetAsync(dp0, 0, vbytes, st));
+    HIP_TRY(ctx, hipMemsetAsync(dp1, 0, vbytes, st));
+    HIP_TRY(ctx, hipMemsetAsync(dseg, 0, (size_t)S * sizeof(double), st));
+    HIP_TRY(ctx, hipMemsetAsync(dA, 0, vbytes, st));
     HIP_TRY(ctx, hipMemcpyAsync(dsc, &hs, sizeof hs, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(dx, x, bytes, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(dr, r, bytes, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(dp, p, bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dseg, r, bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dp0, p, bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(dAp, Ap, bytes, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, cgx::launch_update_xr(n, dp, dAp, dx, dr, dsc, 0, dsc->local, 1, dpart, st));
+    HIP_TRY(ctx, cgx::launch_update_xr(n, dp0, dAp, dx, sv, dsc, 0, &dsc->local[cgx::kSlotConj], 1, dpart, st));
     double rr_host = 0.0;
-    double *drr = nullptr;
-    HIP_TRY(ctx, hipMalloc(&drr, sizeof(double)));
-    HIP_TRY(ctx, cgx::launch_reduce_partials(dpart, grid, drr, nullptr, st));
-    HIP_TRY(ctx, cgx::launch_update_p(n, dr, dp, dsc, 0, 0, -1.0 /* never converges */, dsc->local, 1, st));
+    HIP_TRY(ctx, hipMemcpyAsync(&rr_host, dseg + Sr + cgx::kSlotRr, sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(x, dx, bytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(r, dr, bytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(p, dp, bytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(&rr_host, drr, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(r, dseg, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    // Force the wanted beta: rsold = 1, gathered r.r = beta  =>  K1(k=1) computes beta/1.
+    const double one = 1.0;
+    HIP_TRY(ctx, hipMemcpyAsync(&dsc->rs[0], &one, sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dseg + Sr + cgx::kSlotRr, &beta, sizeof(double), hipMemcpyHostToDevice, st));
+    cgx::GemvPlan plan = cgx::plan_gemv(ctx->cfg.gemv_variant, 1, (int)lda);
+    HIP_TRY(ctx, cgx::launch_gemv_fused(plan, dA, lda, 1, 0, dp0, dp1, sv, dAp1, dpart, dsc, 1, -1.0 /* never converges */, st));
+    HIP_TRY(ctx, hipMemcpyAsync(p, dp1, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (rr) *rr = rr_host;
-    (void)hipFree(dx); (void)hipFree(dr); (void)hipFree(dp); (void)hipFree(dAp); (void)hipFree(dpart);
-    (void)hipFree(dsc); (void)hipFree(drr);
+    (void)hipFree(dx); (void)hipFree(dAp); (void)hipFree(dp0); (void)hipFree(dp1); (void)hipFree(dseg);
+    (void)hipFree(dpart); (void)hipFree(dA); (void)hipFree(dAp1); (void)hipFree(dsc);
     return CGX_OK;
 }
 

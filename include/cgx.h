@@ -58,7 +58,7 @@ typedef struct cgx_config {
     int  gemv_variant;        /* 0 = library default; see DESIGN.md "K1 variants"           */
     int  lda_pad;             /* extra doubles added to the row pitch (-1 = library default)*/
     int  check_every;         /* iterations between host polls of the device `done` flag (0 = default) */
-    int  profile_gemv;        /* 1 = bracket every K1 launch with HIP events                */
+    int  profile_gemv;        /* n > 0 = bracket every n-th K1 launch with HIP events       */
     int  use_graph;           /* 1 = replay the iteration body from a hipGraph              */
     int  reserved[8];
 } cgx_config;
@@ -131,8 +131,10 @@ cgx_status  cgx_solve_end(cgx_ctx *ctx, double *x, cgx_result *res);
  * results in global row order (LOOPBACK/SELF) or this rank's rows at their global offset (RCCL);
  * *pAp receives sum_i p_i * Ap_i over the local rows (the fused cblas_ddot of cg.cc:105). */
 cgx_status  cgx_probe_gemv(cgx_ctx *ctx, const double *p, double *y, double *pAp);
-/* One pass of K3 (cg.cc:110-117) then K4 (cg.cc:124-129) on caller data of length n, single shard:
- * x += alpha p; r -= alpha Ap; *rr = r.r; p = r + beta p. */
+/* Mean duration (ms, HIP events) of `reps` back-to-back launches of the plain K1 on the current matrix. */
+cgx_status  cgx_probe_time_gemv(cgx_ctx *ctx, int reps, double *ms_per_launch);
+/* One pass of K3 (cg.cc:107-116) and of the p update fused into the next K1 (cg.cc:124-129) on caller
+ * data of length n, single shard: x += alpha p; r -= alpha Ap; *rr = r.r; p = r + beta p. */
 cgx_status  cgx_probe_vector_ops(cgx_ctx *ctx, int n, double alpha, double beta, double *x, double *r,
                                  double *p, const double *Ap, double *rr);
 /* Copy this shard's device row block (rows x n, dense, row-major) back to the host. */
