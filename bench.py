@@ -38,6 +38,8 @@ def parse_args():
     ap.add_argument("--matrix-size", dest="n", type=int, default=0, help="matrix size (default 32768; weak mode: floor(16384*sqrt(P)))")
     ap.add_argument("--mode", choices=["strong", "weak"], default="strong")
     ap.add_argument("--variant", type=int, default=0, help="K1 shape override (DESIGN.md)")
+    ap.add_argument("--transport", choices=["auto", "p2p", "rccl"], default="auto",
+                    help="multi-GPU exchange: direct xGMI mailboxes (p2p), RCCL, or p2p with RCCL as fallback (auto)")
     ap.add_argument("--lda-pad", type=int, default=-1)
     ap.add_argument("--cpu-baseline-iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -119,8 +121,6 @@ def main():
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", rank=rank, world_size=world,
                                 device_id=torch.device("cuda", local_rank))
-        # replaces mpirun's wire-up (MPI_Init, cg_main.cc:15-20): every rank gets rank 0's RCCL id
-        uid = broadcast_bytes(dist, pkg.comm_unique_id() if rank == 0 else None, pkg.cgx.UNIQUE_ID_BYTES, "cuda")
 
     if args.n:
         n = args.n
@@ -128,15 +128,15 @@ def main():
         n = int(math.floor(16384 * math.sqrt(world)))   # code/MPI/cg.run:22-44 rounding rule, N^2/P constant
     else:
         n = 32768
+    profile_every = 0 if args.no_profile_gemv else (args.profile_every or (1 if world == 1 else 8))
 
-    solver = pkg.CGSolver(comm_mode=pkg.COMM_RCCL if use_comm else pkg.COMM_SELF, nranks=world, rank=rank,
-                          device=local_rank, unique_id=uid, gemv_variant=args.variant, lda_pad=args.lda_pad,
-                          profile_gemv=0 if args.no_profile_gemv else (args.profile_every or (1 if world == 1 else 8)))
-    solver.generate_lap2d_matrix(n)
-    solver.set_max_iter(args.warmup + args.steps)
-    solver.tolerance(0.0)                  # fixed-iteration run: the break of cg.cc:120 is never taken
-    solver.init_source_term(1.0 / n)
-    x = np.zeros(n)
+    def all_ok(flag):
+        """True only if `flag` is true on every rank (so that all ranks take the same branch)."""
+        if dist is None:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
 
     def sync():
         if dist is not None:
@@ -145,16 +145,93 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    solver.solve_begin(x)
-    solver.solve_steps(args.warmup)
-    sync()
-    t0 = time.perf_counter()
-    solver.solve_steps(args.steps)         # enqueues K loop bodies and synchronises the library's stream
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    res = solver.solve_end(x)
+    def make_solver(transport):
+        """transport: 'self' | 'rccl' | 'p2p'.  Returns a ready solver or None (same answer on every rank)."""
+        common = dict(nranks=world, rank=rank, device=local_rank, gemv_variant=args.variant, lda_pad=args.lda_pad,
+                      profile_gemv=profile_every)
+        s = None
+        ok = True
+        try:
+            if transport == "self":
+                s = pkg.CGSolver(comm_mode=pkg.COMM_SELF, **common)
+            elif transport == "rccl":
+                # replaces mpirun's wire-up (MPI_Init, cg_main.cc:15-20): every rank gets rank 0's RCCL id
+                uid = broadcast_bytes(dist, pkg.comm_unique_id() if rank == 0 else None, pkg.cgx.UNIQUE_ID_BYTES, "cuda")
+                s = pkg.CGSolver(comm_mode=pkg.COMM_RCCL, unique_id=uid, **common)
+            else:
+                s = pkg.CGSolver(comm_mode=pkg.COMM_P2P, **common)
+                mine = torch.tensor(list(s.p2p_export()), dtype=torch.uint8, device="cuda")
+                allh = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(allh, mine)          # every rank's mailbox handle to every rank
+                s.p2p_import(b"".join(bytes(t.cpu().tolist()) for t in allh))
+                dist.barrier()
+                ok = s.p2p_selftest(32)              # pattern all-gathers, verified, every wait bounded
+        except Exception as e:                       # noqa: BLE001 -- any failure means "do not use this transport"
+            print("bench.py rank %d: transport %s unavailable: %s" % (rank, transport, e), file=sys.stderr, flush=True)
+            ok = False
+        if not all_ok(ok):
+            if s is not None:
+                s.close()
+            return None
+        return s
+
+    def run(s):
+        """W warm-up + K timed loop bodies on solver s.  Returns (elapsed, result) or None.  Every rank makes
+        the same sequence of torch.distributed calls whatever fails locally, so a failure cannot desynchronise."""
+        ok = True
+        x = np.zeros(n)
+        try:
+            s.generate_lap2d_matrix(n)
+            s.set_max_iter(args.warmup + args.steps)
+            s.tolerance(0.0)               # fixed-iteration run: the break of cg.cc:120 is never taken
+            s.init_source_term(1.0 / n)
+            s.solve_begin(x)
+            s.solve_steps(args.warmup)
+        except Exception as e:             # noqa: BLE001
+            print("bench.py rank %d: warm-up failed: %s" % (rank, e), file=sys.stderr, flush=True)
+            ok = False
+        if not all_ok(ok):
+            return None
+        sync()
+        t0 = time.perf_counter()
+        try:
+            s.solve_steps(args.steps)      # enqueues K loop bodies and synchronises the library's stream
+        except Exception as e:             # noqa: BLE001
+            print("bench.py rank %d: timed steps failed: %s" % (rank, e), file=sys.stderr, flush=True)
+            ok = False
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        res = None
+        try:
+            res = s.solve_end(x)
+        except Exception as e:             # noqa: BLE001
+            print("bench.py rank %d: solve_end failed: %s" % (rank, e), file=sys.stderr, flush=True)
+            ok = False
+        if not all_ok(ok):
+            return None
+        return elapsed, res
+
+    if not use_comm:
+        order = ["self"]
+    elif args.transport == "auto":
+        order = ["p2p", "rccl"]            # direct-xGMI mailboxes if their self-test passes on this node, else RCCL
+    else:
+        order = [args.transport]
+    solver, out, transport = None, None, None
+    for transport in order:
+        solver = make_solver(transport)
+        if solver is None:
+            continue
+        out = run(solver)
+        if out is not None:
+            break
+        solver.close()
+        solver = None
+    if out is None:
+        sys.exit("bench.py: no transport produced a result")
+    elapsed, res = out
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -187,7 +264,10 @@ def main():
                 "workload": "generate_lap2d_matrix N=%d, init_source_term(1/N), fixed-iteration dense fp64 CG "
                             "(BASELINE.json configs[%d])" % (n, 2 if world == 1 else (3 if args.mode == "strong" else 4)),
                 "n": n, "rows_per_gpu": rows0, "parallelism": "rowblock%d" % world,
-                "collectives": "RCCL allgather(scalars) x2 + allgather(p) per iteration" if use_comm else "none",
+                "collectives": {"self": "none",
+                                "rccl": "2 x ncclAllGather per iteration (K1 partials; [r slice | r.r])",
+                                "p2p": "2 x mailbox all-gather kernel per iteration over IPC/xGMI (K1 partials; [r slice | r.r])"}[transport],
+                "transport": transport,
                 "k1_variant": args.variant,
             },
             "roofline": {

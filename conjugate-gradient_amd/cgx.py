@@ -14,10 +14,12 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libcgx.so")
 UNIQUE_ID_BYTES = 128
 
-COMM_SELF, COMM_LOOPBACK, COMM_RCCL = 0, 1, 2
+IPC_HANDLE_BYTES = 64
+COMM_SELF, COMM_LOOPBACK, COMM_RCCL, COMM_P2P = 0, 1, 2, 3
 
 EXPORTS = [
     "cgx_config_init", "cgx_comm_unique_id", "cgx_create", "cgx_destroy", "cgx_last_error", "cgx_status_string",
+    "cgx_p2p_export", "cgx_p2p_import", "cgx_p2p_selftest",
     "cgx_partition", "cgx_generate_lap2d_matrix", "cgx_set_matrix_dense", "cgx_read_matrix",
     "cgx_init_source_term", "cgx_set_source_term", "cgx_set_max_iter", "cgx_set_tolerance", "cgx_get_size",
     "cgx_solve", "cgx_solve_begin", "cgx_solve_steps", "cgx_solve_end",
@@ -30,7 +32,7 @@ class Config(C.Structure):
         ("struct_version", C.c_int), ("comm_mode", C.c_int), ("device", C.c_int), ("rank", C.c_int),
         ("nranks", C.c_int), ("unique_id", C.c_ubyte * UNIQUE_ID_BYTES), ("gemv_variant", C.c_int),
         ("lda_pad", C.c_int), ("check_every", C.c_int), ("profile_gemv", C.c_int), ("use_graph", C.c_int),
-        ("reserved", C.c_int * 8),
+        ("p2p_mailbox_kib", C.c_int), ("p2p_timeout_ms", C.c_int), ("reserved", C.c_int * 6),
     ]
 
 
@@ -83,6 +85,9 @@ def lib():
         L.cgx_last_error.restype = C.c_char_p
         L.cgx_status_string.argtypes = [C.c_int]
         L.cgx_status_string.restype = C.c_char_p
+        L.cgx_p2p_export.argtypes = [vp, C.POINTER(C.c_ubyte)]
+        L.cgx_p2p_import.argtypes = [vp, C.POINTER(C.c_ubyte)]
+        L.cgx_p2p_selftest.argtypes = [vp, C.c_int, ip]
         L.cgx_partition.argtypes = [C.c_int, C.c_int, ip, ip]
         L.cgx_generate_lap2d_matrix.argtypes = [vp, C.c_int]
         L.cgx_set_matrix_dense.argtypes = [vp, dp, C.c_long, C.c_int]
@@ -138,7 +143,7 @@ class CGSolver:
     """
 
     def __init__(self, comm_mode=COMM_SELF, nranks=1, rank=0, device=0, unique_id=None, gemv_variant=0,
-                 lda_pad=-1, check_every=0, profile_gemv=False):
+                 lda_pad=-1, check_every=0, profile_gemv=False, p2p_timeout_ms=0, p2p_mailbox_kib=0):
         L = lib()
         cfg = Config()
         L.cgx_config_init(C.byref(cfg))
@@ -150,6 +155,8 @@ class CGSolver:
         cfg.lda_pad = lda_pad
         cfg.check_every = check_every
         cfg.profile_gemv = int(profile_gemv)   # n > 0: every n-th K1 launch is event-timed
+        cfg.p2p_timeout_ms = p2p_timeout_ms
+        cfg.p2p_mailbox_kib = p2p_mailbox_kib
         if unique_id is not None:
             assert len(unique_id) == UNIQUE_ID_BYTES
             C.memmove(cfg.unique_id, bytes(unique_id), UNIQUE_ID_BYTES)
@@ -182,6 +189,23 @@ class CGSolver:
 
     def __exit__(self, *exc):
         self.close()
+
+    # -- direct peer exchange wire-up (COMM_P2P) ------------------------------------------------------
+    def p2p_export(self):
+        buf = (C.c_ubyte * IPC_HANDLE_BYTES)()
+        self._check(lib().cgx_p2p_export(self._h, buf))
+        return bytes(buf)
+
+    def p2p_import(self, handles):
+        """handles: bytes of length nranks*64, rank order (every rank's p2p_export())."""
+        assert len(handles) == self.nranks * IPC_HANDLE_BYTES
+        buf = (C.c_ubyte * len(handles)).from_buffer_copy(handles)
+        self._check(lib().cgx_p2p_import(self._h, buf))
+
+    def p2p_selftest(self, rounds=32):
+        ok = C.c_int()
+        self._check(lib().cgx_p2p_selftest(self._h, int(rounds), C.byref(ok)))
+        return bool(ok.value)
 
     # -- reference interface --------------------------------------------------------------------
     def generate_lap2d_matrix(self, size):

@@ -101,6 +101,26 @@ hipError_t launch_generate_lap2d(double *A, long lda, int size, int row0, int ro
 hipError_t launch_scatter_coo(double *A, long lda, int row0, const int *I, const int *J, const double *a, long nz,
                               hipStream_t s);
 
+// ---- direct peer exchange (CGX_COMM_P2P): a lean all-gather over IPC-mapped mailboxes ---------------------
+// Every rank owns one fine-grained mailbox; all ranks map all mailboxes.  Layout (identical on every rank):
+//   flags : [kP2pChannels][kMaxRanks] words, one 128-B line each   (flag[c][q] = last epoch rank q delivered on channel c)
+//   data  : per channel c, [2 parities][nranks] slots of slot_bytes[c]
+constexpr int kP2pChannels = 3;          // 0 = K1 partials, 1 = [r | r.r] segments, 2 = DEBUG scalars
+constexpr int kP2pFlagStride = 128;      // bytes between flag words
+struct MailboxView {
+    unsigned char *base[kMaxRanks];      // base[q] = rank q's mailbox as mapped in THIS process (base[rank] = own)
+    long data_off[kP2pChannels];         // byte offset of channel c's data area
+    long slot_bytes[kP2pChannels];       // bytes per (parity, rank) slot
+    int nranks, rank;
+};
+
+// All-gather `count` doubles per rank: rank's own contribution is src; afterwards dst + q*dst_stride holds
+// rank q's for every q (own part copied from src only if copy_self).  One workgroup per peer: push my data +
+// release + flag into the peer's mailbox, wait (bounded) for the peer's flag in mine, copy its data out.
+hipError_t launch_mailbox_allgather(const MailboxView &mv, int chan, unsigned long long epoch, const double *src,
+                                    int count, double *dst, long dst_stride, int copy_self,
+                                    long long timeout_ticks, int *err, hipStream_t s);
+
 // Loopback "collective": copy local[kSlots] of every shard into gathered[] of every shard (<= 16 shards).
 hipError_t launch_loopback_gather(double *const *gathered_ptrs, const Scalars *const *scalar_ptrs, int nshards,
                                   hipStream_t s);

@@ -609,6 +609,80 @@ __global__ void k_loopback_gather(double *const *gathered_ptrs, const Scalars *c
 }
 
 // ------------------------------------------------------------------------------------------------
+// Direct peer exchange over xGMI: replaces one RCCL all-gather launch.
+// Protocol per (channel, epoch), placement independent:
+//   producer: plain 16-B stores of the payload into the PEER's mailbox slot [epoch&1][my rank]; every storing
+//             thread fences at system scope; workgroup barrier; one lane stores flag = epoch with a system-scope
+//             release atomic into the peer's flag word [channel][my rank];
+//   consumer: one lane polls its OWN flag word [channel][peer] with system-scope acquire loads (bounded by the
+//             100 MHz wall clock), workgroup barrier, every thread fences (acquire, system) and reads the slot
+//             with system-scope loads (never served from a stale cache line), then plain-stores into the
+//             ordinary working buffer the next kernel reads.
+// Two parities suffice: a rank can start epoch e+2 only after every peer delivered e+1, which a peer does only
+// after the kernel that consumed epoch e on that peer has finished (stream order).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mailbox_allgather(MailboxView mv, int chan, unsigned long long epoch,
+                                                            const double *__restrict__ src, int count,
+                                                            double *__restrict__ dst, long dst_stride, int copy_self,
+                                                            long long timeout_ticks, int *err)
+{
+    const int peer = blockIdx.x;
+    const int tid = threadIdx.x;
+    if (*reinterpret_cast<volatile int *>(err)) return;   // an earlier wait expired: do not wait again, let the host see it
+    if (peer == mv.rank) {
+        if (copy_self)
+            for (int i = tid; i < count; i += 256) dst[(long)mv.rank * dst_stride + i] = src[i];
+        return;
+    }
+    const int parity = (int)(epoch & 1);
+    const long slot = mv.slot_bytes[chan];
+    // ---- push my contribution into the peer's mailbox --------------------------------------------------
+    {
+        double *out = reinterpret_cast<double *>(mv.base[peer] + mv.data_off[chan] +
+                                                 ((long)parity * mv.nranks + mv.rank) * slot);
+        const int pairs = count >> 1;
+        for (int i = tid; i < pairs; i += 256)
+            *reinterpret_cast<d2 *>(out + 2 * i) = *reinterpret_cast<const d2 *>(src + 2 * i);
+        if ((count & 1) && tid == 0) out[count - 1] = src[count - 1];
+        __threadfence_system();   // release: my stores are visible system-wide before the flag below
+        __syncthreads();
+        if (tid == 0) {
+            unsigned long long *flag = reinterpret_cast<unsigned long long *>(
+                mv.base[peer] + ((long)chan * kMaxRanks + mv.rank) * kP2pFlagStride);
+            __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    // ---- wait for the peer's contribution in MY mailbox, then copy it out ------------------------------------
+    __shared__ int s_ok;
+    if (tid == 0) {
+        const unsigned long long *flag = reinterpret_cast<const unsigned long long *>(
+            mv.base[mv.rank] + ((long)chan * kMaxRanks + peer) * kP2pFlagStride);
+        const long long t0 = wall_clock64();
+        int ok = 1;
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > timeout_ticks) {   // every spin is bounded: give up, tell the host
+                ok = 0;
+                atomicExch(err, 1);
+                break;
+            }
+        }
+        s_ok = ok;
+    }
+    __syncthreads();
+    if (!s_ok) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope
+    {
+        const unsigned long long *in = reinterpret_cast<const unsigned long long *>(
+            mv.base[mv.rank] + mv.data_off[chan] + ((long)parity * mv.nranks + peer) * slot);
+        double *out = dst + (long)peer * dst_stride;
+        for (int i = tid; i < count; i += 256)
+            out[i] = __longlong_as_double(
+                (long long)__hip_atomic_load(in + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------------
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
@@ -791,6 +865,15 @@ hipError_t launch_scatter_coo(double *A, long lda, int row0, const int *I, const
     if (nz <= 0) return hipSuccess;
     int grid = (int)((nz + 255) / 256 < 2048 ? (nz + 255) / 256 : 2048);
     hipLaunchKernelGGL(k_scatter_coo, dim3(grid), dim3(256), 0, s, A, lda, row0, I, J, a, nz);
+    return hipGetLastError();
+}
+
+hipError_t launch_mailbox_allgather(const MailboxView &mv, int chan, unsigned long long epoch, const double *src,
+                                    int count, double *dst, long dst_stride, int copy_self, long long timeout_ticks,
+                                    int *err, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_mailbox_allgather, dim3(mv.nranks), dim3(256), 0, s, mv, chan, epoch, src, count, dst,
+                       dst_stride, copy_self, timeout_ticks, err);
     return hipGetLastError();
 }
 

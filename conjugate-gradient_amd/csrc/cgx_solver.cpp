@@ -83,6 +83,15 @@ struct cgx_ctx {
     // RCCL
     const cgx::RcclApi *rccl = nullptr;
     ncclComm_t comm = nullptr;
+    // direct peer exchange (CGX_COMM_P2P)
+    unsigned char *mailbox = nullptr;        // own fine-grained mailbox
+    size_t mailbox_bytes = 0;
+    bool p2p_ready = false;                  // peers' mailboxes are mapped
+    cgx::MailboxView mv{};
+    unsigned long long p2p_epoch[cgx::kP2pChannels] = {0, 0, 0};
+    int *d_p2p_err = nullptr;                // device word set when a bounded wait expired
+    long long p2p_timeout_ticks = 0;         // 100 MHz wall-clock ticks
+
     int seg_S = 0, seg_Sr = 0;   // exchange segment geometry (equal for all ranks)
     int npart = 0;               // K1 partials per rank in exchange 1 (max grid over ranks)
 
@@ -223,11 +232,26 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
     ctx->npart = 1;
     for (int q = 0; q < ctx->nranks; ++q)
         ctx->npart = std::max(ctx->npart, cgx::plan_gemv(variant, ctx->num_rows[q], (int)ctx->lda).grid);
+    if (ctx->cfg.comm_mode == CGX_COMM_P2P) {
+        // mailbox layout of this problem: flags, then per channel [2 parities][nranks] slots
+        const long flags_bytes = (long)cgx::kP2pChannels * cgx::kMaxRanks * cgx::kP2pFlagStride;
+        const long slot[cgx::kP2pChannels] = {((long)ctx->npart * 8 + 15) / 16 * 16, ((long)ctx->seg_S * 8 + 15) / 16 * 16,
+                                              (long)cgx::kSlots * 8};
+        long off = flags_bytes;
+        for (int c = 0; c < cgx::kP2pChannels; ++c) {
+            ctx->mv.data_off[c] = off;
+            ctx->mv.slot_bytes[c] = slot[c];
+            off += 2L * ctx->nranks * slot[c];
+        }
+        if ((size_t)off > ctx->mailbox_bytes)
+            return fail(ctx, CGX_ERR_P2P, "mailbox too small for this problem: need " + std::to_string(off) +
+                                              " bytes (raise cgx_config.p2p_mailbox_kib)");
+    }
     const int nlocal = (ctx->cfg.comm_mode == CGX_COMM_LOOPBACK) ? ctx->nranks : 1;
     ctx->shards.resize(nlocal);
     for (int i = 0; i < nlocal; ++i) {
         Shard &s = ctx->shards[i];
-        s.rank = (ctx->cfg.comm_mode == CGX_COMM_RCCL) ? ctx->cfg.rank : i;
+        s.rank = (ctx->cfg.comm_mode == CGX_COMM_RCCL || ctx->cfg.comm_mode == CGX_COMM_P2P) ? ctx->cfg.rank : i;
         s.row0 = ctx->start_rows[s.rank];
         s.rows = ctx->num_rows[s.rank];
         s.plan = cgx::plan_gemv(variant, s.rows, (int)ctx->lda);
@@ -280,6 +304,19 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
 
 // ---- collectives ---------------------------------------------------------------------------------
 
+// CGX_COMM_P2P: one lean all-gather kernel over the IPC-mapped mailboxes (cgx_kernels.hip).
+cgx_status p2p_allgather(cgx_ctx *ctx, int chan, const double *src, int count, double *dst, long dst_stride,
+                         int copy_self)
+{
+    if (!ctx->p2p_ready) return fail(ctx, CGX_ERR_P2P, "cgx_p2p_import has not been called");
+    if ((long)count * 8 > ctx->mv.slot_bytes[chan]) return fail(ctx, CGX_ERR_P2P, "p2p payload larger than its slot");
+    const unsigned long long epoch = ++ctx->p2p_epoch[chan];
+    HIP_TRY(ctx, cgx::launch_mailbox_allgather(ctx->mv, chan, epoch, src, count, dst, dst_stride, copy_self,
+                                               ctx->p2p_timeout_ticks, ctx->d_p2p_err, ctx->stream));
+    return CGX_OK;
+}
+
+
 // Scalars: every shard contributes sc->local[kSlots]; afterwards every shard's gathered[] holds all of them.
 // Replaces MPI_Allreduce (cg.cc:92,106,117).  In SELF mode the consumers read sc->local directly.
 cgx_status gather_scalars(cgx_ctx *ctx)
@@ -290,6 +327,10 @@ cgx_status gather_scalars(cgx_ctx *ctx)
     case CGX_COMM_LOOPBACK:
         HIP_TRY(ctx, cgx::launch_loopback_gather(ctx->d_gathered_ptrs, ctx->d_scalar_ptrs, ctx->nranks, ctx->stream));
         return CGX_OK;
+    case CGX_COMM_P2P: {
+        Shard &s = ctx->shards[0];
+        return p2p_allgather(ctx, 2, s.sc->local, cgx::kSlots, s.gathered, cgx::kSlots, 1);
+    }
     default: {
         Shard &s = ctx->shards[0];
         NCCL_TRY(ctx, ctx->rccl->AllGather(s.sc->local, s.gathered, cgx::kSlots, ncclDouble, ctx->comm, ctx->stream));
@@ -312,6 +353,10 @@ cgx_status gather_k1_partials(cgx_ctx *ctx)
                 HIP_TRY(ctx, hipMemcpyAsync(dst.k1_gath + src.rank * np, src.k1_part, np * sizeof(double),
                                             hipMemcpyDeviceToDevice, ctx->stream));
         return CGX_OK;
+    case CGX_COMM_P2P: {
+        Shard &s = ctx->shards[0];
+        return p2p_allgather(ctx, 0, s.k1_part, ctx->npart, s.k1_gath, ctx->npart, 1);
+    }
     default: {
         Shard &s = ctx->shards[0];
         NCCL_TRY(ctx, ctx->rccl->AllGather(s.k1_part, s.k1_gath, np, ncclDouble, ctx->comm, ctx->stream));
@@ -336,6 +381,10 @@ cgx_status gather_segments(cgx_ctx *ctx)
                     HIP_TRY(ctx, hipMemcpyAsync(dst.rg + src.rank * S, src.rg + src.rank * S, S * sizeof(double),
                                                 hipMemcpyDeviceToDevice, ctx->stream));
         return CGX_OK;
+    case CGX_COMM_P2P: {
+        Shard &s = ctx->shards[0];
+        return p2p_allgather(ctx, 1, s.rg + s.rank * S, ctx->seg_S, s.rg, ctx->seg_S, 0);
+    }
     default: {
         Shard &s = ctx->shards[0];
         NCCL_TRY(ctx, ctx->rccl->AllGather(s.rg + s.rank * S, s.rg, S, ncclDouble, ctx->comm, ctx->stream));
@@ -409,6 +458,16 @@ cgx_status enqueue_iteration(cgx_ctx *ctx, int k)
     return CGX_OK;
 }
 
+// After a stream sync: did any bounded wait of the direct peer exchange expire?
+cgx_status check_p2p_error(cgx_ctx *ctx)
+{
+    if (ctx->cfg.comm_mode != CGX_COMM_P2P || !ctx->d_p2p_err) return CGX_OK;
+    int e = 0;
+    HIP_TRY(ctx, hipMemcpy(&e, ctx->d_p2p_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (e) return fail(ctx, CGX_ERR_P2P, "direct peer exchange: a wait for a peer's flag expired (peer dead or IPC not coherent)");
+    return CGX_OK;
+}
+
 cgx_status read_flags_sync(cgx_ctx *ctx)
 {
     Shard &s = ctx->shards[0];
@@ -417,7 +476,7 @@ cgx_status read_flags_sync(cgx_ctx *ctx)
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->done = flags[0] != 0;
     ctx->k_final = flags[1];
-    return CGX_OK;
+    return check_p2p_error(ctx);
 }
 
 }  // namespace
@@ -450,6 +509,7 @@ const char *cgx_status_string(cgx_status s)
     case CGX_ERR_OOM: return "out of memory";
     case CGX_ERR_NO_DEVICE: return "no usable GPU (libcgx has no CPU fallback)";
     case CGX_ERR_UNSUPPORTED: return "unsupported input";
+    case CGX_ERR_P2P: return "direct peer exchange failed";
     }
     return "unknown";
 }
@@ -490,9 +550,10 @@ cgx_status cgx_create(cgx_ctx **out, const cgx_config *cfg_in)
         return fail(nullptr, CGX_ERR_BAD_ARG, "CGX_COMM_SELF requires nranks == 1");
     if (cfg.comm_mode == CGX_COMM_LOOPBACK && cfg.nranks > 16)
         return fail(nullptr, CGX_ERR_BAD_ARG, "CGX_COMM_LOOPBACK supports at most 16 logical shards");
-    if (cfg.comm_mode == CGX_COMM_RCCL && (cfg.rank < 0 || cfg.rank >= cfg.nranks || cfg.nranks > cgx::kMaxRanks))
-        return fail(nullptr, CGX_ERR_BAD_ARG, "CGX_COMM_RCCL: rank out of range or nranks > 64");
-    if (cfg.comm_mode < CGX_COMM_SELF || cfg.comm_mode > CGX_COMM_RCCL)
+    if ((cfg.comm_mode == CGX_COMM_RCCL || cfg.comm_mode == CGX_COMM_P2P) &&
+        (cfg.rank < 0 || cfg.rank >= cfg.nranks || cfg.nranks > cgx::kMaxRanks))
+        return fail(nullptr, CGX_ERR_BAD_ARG, "CGX_COMM_RCCL/P2P: rank out of range or nranks > 64");
+    if (cfg.comm_mode < CGX_COMM_SELF || cfg.comm_mode > CGX_COMM_P2P)
         return fail(nullptr, CGX_ERR_BAD_ARG, "unknown comm_mode");
 
     int ndev = 0;
@@ -553,7 +614,94 @@ cgx_status cgx_create(cgx_ctx **out, const cgx_config *cfg_in)
             return bail(CGX_ERR_RCCL);
         }
     }
+    if (cfg.comm_mode == CGX_COMM_P2P) {
+        ctx->mailbox_bytes = (size_t)(cfg.p2p_mailbox_kib > 0 ? cfg.p2p_mailbox_kib : 4096) * 1024;
+        ctx->p2p_timeout_ticks = (long long)(cfg.p2p_timeout_ms > 0 ? cfg.p2p_timeout_ms : 5000) * 100000LL;   // 100 MHz
+        // fine-grained: stores from peers and system-scope atomics are coherent without a kernel boundary
+        if (hipExtMallocWithFlags(reinterpret_cast<void **>(&ctx->mailbox), ctx->mailbox_bytes, hipDeviceMallocFinegrained) != hipSuccess ||
+            hipMemset(ctx->mailbox, 0, ctx->mailbox_bytes) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&ctx->d_p2p_err), sizeof(int)) != hipSuccess ||
+            hipMemset(ctx->d_p2p_err, 0, sizeof(int)) != hipSuccess) {
+            ctx->err = "mailbox allocation failed";
+            return bail(CGX_ERR_P2P);
+        }
+        ctx->mv.nranks = cfg.nranks;
+        ctx->mv.rank = cfg.rank;
+        ctx->mv.base[cfg.rank] = ctx->mailbox;
+        if (cfg.nranks == 1) ctx->p2p_ready = true;
+    }
     *out = ctx;
+    return CGX_OK;
+}
+
+cgx_status cgx_p2p_export(cgx_ctx *ctx, unsigned char out[CGX_IPC_HANDLE_BYTES])
+{
+    static_assert(sizeof(hipIpcMemHandle_t) == CGX_IPC_HANDLE_BYTES, "hipIpcMemHandle_t size");
+    if (!ctx || !out || ctx->cfg.comm_mode != CGX_COMM_P2P) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_p2p_export: not a P2P context");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipIpcMemHandle_t h;
+    HIP_TRY(ctx, hipIpcGetMemHandle(&h, ctx->mailbox));
+    memcpy(out, &h, CGX_IPC_HANDLE_BYTES);
+    return CGX_OK;
+}
+
+cgx_status cgx_p2p_import(cgx_ctx *ctx, const unsigned char *handles)
+{
+    if (!ctx || !handles || ctx->cfg.comm_mode != CGX_COMM_P2P) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_p2p_import: not a P2P context");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int q = 0; q < ctx->nranks; ++q) {
+        if (q == ctx->cfg.rank) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, handles + (size_t)q * CGX_IPC_HANDLE_BYTES, CGX_IPC_HANDLE_BYTES);
+        void *ptr = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess)
+            return fail(ctx, CGX_ERR_P2P, std::string("hipIpcOpenMemHandle(rank ") + std::to_string(q) + "): " + hipGetErrorString(e));
+        ctx->mv.base[q] = static_cast<unsigned char *>(ptr);
+    }
+    ctx->p2p_ready = true;
+    return CGX_OK;
+}
+
+cgx_status cgx_p2p_selftest(cgx_ctx *ctx, int rounds, int *ok)
+{
+    if (!ctx || !ok || rounds <= 0 || ctx->cfg.comm_mode != CGX_COMM_P2P) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_p2p_selftest: bad argument");
+    *ok = 0;
+    if (!ctx->p2p_ready) return fail(ctx, CGX_ERR_P2P, "cgx_p2p_import has not been called");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int P = ctx->nranks, me = ctx->cfg.rank;
+    const int count = 1024;   // doubles per rank: 8 KiB, the size class of the real exchanges
+    cgx::MailboxView saved = ctx->mv;
+    ctx->mv.data_off[1] = (long)cgx::kP2pChannels * cgx::kMaxRanks * cgx::kP2pFlagStride;
+    ctx->mv.slot_bytes[1] = (long)count * 8;
+    if ((size_t)(ctx->mv.data_off[1] + 2L * P * count * 8) > ctx->mailbox_bytes) {
+        ctx->mv = saved;
+        return fail(ctx, CGX_ERR_P2P, "mailbox too small for the self-test");
+    }
+    double *dsrc = nullptr, *ddst = nullptr;
+    HIP_TRY(ctx, hipMalloc(&dsrc, (size_t)count * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc(&ddst, (size_t)P * count * sizeof(double)));
+    std::vector<double> hsrc(count), hdst((size_t)P * count);
+    bool good = true;
+    cgx_status st = CGX_OK;
+    for (int r = 0; r < rounds && good; ++r) {
+        for (int i = 0; i < count; ++i) hsrc[i] = 1e6 * (me + 1) + 1e3 * r + i + 0.25;
+        HIP_TRY(ctx, hipMemcpyAsync(dsrc, hsrc.data(), count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ddst, 0, (size_t)P * count * sizeof(double), ctx->stream));
+        st = p2p_allgather(ctx, 1, dsrc, count, ddst, count, 1);
+        if (st != CGX_OK) break;
+        HIP_TRY(ctx, hipMemcpyAsync(hdst.data(), ddst, (size_t)P * count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (check_p2p_error(ctx) != CGX_OK) { good = false; break; }
+        for (int q = 0; q < P && good; ++q)
+            for (int i = 0; i < count; ++i)
+                if (hdst[(size_t)q * count + i] != 1e6 * (q + 1) + 1e3 * r + i + 0.25) { good = false; break; }
+    }
+    (void)hipFree(dsrc);
+    (void)hipFree(ddst);
+    ctx->mv = saved;
+    if (st != CGX_OK) return st;
+    *ok = good ? 1 : 0;
     return CGX_OK;
 }
 
@@ -564,6 +712,12 @@ cgx_status cgx_destroy(cgx_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_problem(ctx);
     if (ctx->comm && ctx->rccl) (void)ctx->rccl->CommDestroy(ctx->comm);
+    if (ctx->cfg.comm_mode == CGX_COMM_P2P) {
+        for (int q = 0; q < ctx->nranks; ++q)
+            if (q != ctx->cfg.rank && ctx->mv.base[q]) (void)hipIpcCloseMemHandle(ctx->mv.base[q]);
+        if (ctx->mailbox) (void)hipFree(ctx->mailbox);
+        if (ctx->d_p2p_err) (void)hipFree(ctx->d_p2p_err);
+    }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (auto e : ctx->flag_ev)
         if (e) (void)hipEventDestroy(e);

@@ -30,6 +30,7 @@ extern "C" {
 
 #define CGX_VERSION 1
 #define CGX_UNIQUE_ID_BYTES 128
+#define CGX_IPC_HANDLE_BYTES 64
 
 typedef enum cgx_status {
     CGX_OK = 0,
@@ -39,13 +40,17 @@ typedef enum cgx_status {
     CGX_ERR_RCCL = 4,         /* an RCCL call failed or librccl could not be loaded         */
     CGX_ERR_OOM = 5,          /* host or device allocation failed                           */
     CGX_ERR_NO_DEVICE = 6,    /* no gfx950 device visible: the product path has NO CPU fallback */
-    CGX_ERR_UNSUPPORTED = 7   /* e.g. Matrix-Market field/format this reader does not take  */
+    CGX_ERR_UNSUPPORTED = 7,  /* e.g. Matrix-Market field/format this reader does not take  */
+    CGX_ERR_P2P = 8           /* direct peer exchange: a bounded wait for a peer expired, or IPC mapping failed */
 } cgx_status;
 
 typedef enum cgx_comm_mode {
     CGX_COMM_SELF = 0,        /* 1 shard, 1 device, no collectives (psize == 1)             */
     CGX_COMM_LOOPBACK = 1,    /* nranks logical shards on one device, in-process exchange   */
-    CGX_COMM_RCCL = 2         /* this process is shard `rank` of `nranks`, RCCL over xGMI   */
+    CGX_COMM_RCCL = 2,        /* this process is shard `rank` of `nranks`, RCCL over xGMI   */
+    CGX_COMM_P2P = 3          /* same process model, but the two exchanges per iteration are a lean all-gather
+                                 kernel storing straight into the peers' IPC-mapped mailboxes (no RCCL at all);
+                                 needs cgx_p2p_export / cgx_p2p_import after cgx_create                       */
 } cgx_comm_mode;
 
 typedef struct cgx_config {
@@ -60,7 +65,9 @@ typedef struct cgx_config {
     int  check_every;         /* iterations between host polls of the device `done` flag (0 = default) */
     int  profile_gemv;        /* n > 0 = bracket every n-th K1 launch with HIP events       */
     int  use_graph;           /* 1 = replay the iteration body from a hipGraph              */
-    int  reserved[8];
+    int  p2p_mailbox_kib;     /* CGX_COMM_P2P: mailbox size in KiB (0 = 4096)               */
+    int  p2p_timeout_ms;      /* CGX_COMM_P2P: bound of every in-kernel wait (0 = 5000)     */
+    int  reserved[6];
 } cgx_config;
 
 typedef struct cgx_result {
@@ -88,6 +95,14 @@ cgx_status  cgx_create(cgx_ctx **out, const cgx_config *cfg);
 cgx_status  cgx_destroy(cgx_ctx *ctx);
 const char *cgx_last_error(const cgx_ctx *ctx);               /* ctx may be NULL: error of the last failed cgx_create on this thread */
 const char *cgx_status_string(cgx_status s);
+
+/* ---- CGX_COMM_P2P wire-up (replaces MPI_Init's job for the direct-xGMI transport) --------- */
+/* export: this rank's mailbox as an IPC handle.  import: all ranks' handles, rank order (nranks * 64 bytes),
+ * gathered by the launcher (torch.distributed, MPI_Allgather, pipes ...).  selftest: `rounds` all-gathers of
+ * a known pattern, verified on every rank; *ok = 0 on any mismatch or expired wait (then use CGX_COMM_RCCL). */
+cgx_status  cgx_p2p_export(cgx_ctx *ctx, unsigned char out[CGX_IPC_HANDLE_BYTES]);
+cgx_status  cgx_p2p_import(cgx_ctx *ctx, const unsigned char *handles);
+cgx_status  cgx_p2p_selftest(cgx_ctx *ctx, int rounds, int *ok);
 
 /* ---- CGSolver::partition_matrix, code/MPI/cg.cc:236-268 (pure host function) ------------- */
 cgx_status  cgx_partition(int n, int psize, int *start_rows, int *num_rows);

@@ -1,0 +1,59 @@
+"""Worker for tests/test_gpu_p2p.py: one OS process per rank, all on ONE GPU, exchanging through the
+CGX_COMM_P2P mailboxes (hipIpc) -- the direct-xGMI transport rehearsed without a multi-GPU node.
+Control plane (handle exchange, verdict) over gloo.  argv: n max_iter out.json [variant]"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as g  # noqa: E402
+
+
+def main():
+    n, max_iter, out_path = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    variant = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    assert torch.cuda.is_available()
+    pkg = g.load_package()
+    s = pkg.CGSolver(comm_mode=pkg.COMM_P2P, nranks=world, rank=rank, device=0, gemv_variant=variant, p2p_timeout_ms=20000)
+    mine = torch.tensor(list(s.p2p_export()), dtype=torch.uint8)
+    allh = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(allh, mine)
+    s.p2p_import(b"".join(bytes(t.tolist()) for t in allh))
+    dist.barrier()
+    ok = s.p2p_selftest(16)
+    s.generate_lap2d_matrix(n)
+    s.set_max_iter(max_iter)
+    s.init_source_term(1.0 / n)
+    x = np.zeros(n)
+    dist.barrier()
+    res = s.solve(x)
+    # every rank must hold the same full solution and the same scalars
+    xs = [torch.zeros(n, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(xs, torch.from_numpy(x.copy()))
+    same_x = all(torch.equal(xs[0], t) for t in xs)
+    sc = torch.tensor([res["iterations"], res["residual_prev"], res["x_norm"], float(ok)], dtype=torch.float64)
+    scs = [torch.zeros_like(sc) for _ in range(world)]
+    dist.all_gather(scs, sc)
+    same_sc = all(torch.equal(scs[0], t) for t in scs)
+    if rank == 0:
+        O = g.load_oracle()
+        xo, ro = O.solve_lap2d(n, max_iter, 1e-10, world)
+        json.dump({"world": world, "n": n, "selftest_ok": bool(ok), "ranks_agree": bool(same_x and same_sc),
+                   "k": res["iterations"], "k_oracle": ro["iterations"], "converged": res["converged"],
+                   "dx": float(np.linalg.norm(x - xo) / np.linalg.norm(xo)),
+                   "residual_rel": float(abs(res["residual_prev"] - ro["residual_prev"]) / ro["residual_prev"]),
+                   "seconds_solve": res["seconds_solve"]}, open(out_path, "w"))
+    s.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
