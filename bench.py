@@ -117,10 +117,16 @@ def main():
     # Under torch.distributed.run (RANK set) the RCCL path is used even for one rank, so that the launcher
     # plumbing and the collectives can be rehearsed on a one-GPU box; plain `python bench.py` has no comm.
     use_comm = world > 1 or ("RANK" in os.environ and os.environ.get("CGX_BENCH_FORCE_SELF") != "1")
+    ctl = "cuda"   # device of the small control-plane tensors
     if use_comm:
         import torch.distributed as dist
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("CGX_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of world > 1 on a one-GPU box
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            ctl = "cpu"
 
     if args.n:
         n = args.n
@@ -134,7 +140,7 @@ def main():
         """True only if `flag` is true on every rank (so that all ranks take the same branch)."""
         if dist is None:
             return bool(flag)
-        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cuda")
+        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item())
 
@@ -156,11 +162,11 @@ def main():
                 s = pkg.CGSolver(comm_mode=pkg.COMM_SELF, **common)
             elif transport == "rccl":
                 # replaces mpirun's wire-up (MPI_Init, cg_main.cc:15-20): every rank gets rank 0's RCCL id
-                uid = broadcast_bytes(dist, pkg.comm_unique_id() if rank == 0 else None, pkg.cgx.UNIQUE_ID_BYTES, "cuda")
+                uid = broadcast_bytes(dist, pkg.comm_unique_id() if rank == 0 else None, pkg.cgx.UNIQUE_ID_BYTES, ctl)
                 s = pkg.CGSolver(comm_mode=pkg.COMM_RCCL, unique_id=uid, **common)
             else:
                 s = pkg.CGSolver(comm_mode=pkg.COMM_P2P, **common)
-                mine = torch.tensor(list(s.p2p_export()), dtype=torch.uint8, device="cuda")
+                mine = torch.tensor(list(s.p2p_export()), dtype=torch.uint8, device=ctl)
                 allh = [torch.zeros_like(mine) for _ in range(world)]
                 dist.all_gather(allh, mine)          # every rank's mailbox handle to every rank
                 s.p2p_import(b"".join(bytes(t.cpu().tolist()) for t in allh))
@@ -209,6 +215,17 @@ def main():
         except Exception as e:             # noqa: BLE001
             print("bench.py rank %d: solve_end failed: %s" % (rank, e), file=sys.stderr, flush=True)
             ok = False
+        if ok and dist is not None:
+            # every rank must have reached bit-identical scalars (a stale or torn exchange would break this)
+            mine = torch.tensor([res["iterations"], res["residual_prev"], res["x_norm"]], dtype=torch.float64, device=ctl)
+            allv = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allv, mine)
+            if not all(torch.equal(allv[0], v) for v in allv) or not math.isfinite(res["residual_prev"]):
+                print("bench.py rank %d: ranks disagree on the result" % rank, file=sys.stderr, flush=True)
+                ok = False
+        elif dist is not None:
+            dummy = torch.zeros(3, dtype=torch.float64, device=ctl)
+            dist.all_gather([torch.zeros_like(dummy) for _ in range(world)], dummy)
         if not all_ok(ok):
             return None
         return elapsed, res
@@ -234,10 +251,10 @@ def main():
     elapsed, res = out
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        g_ms = torch.tensor([res["gemv_ms_avg"]], dtype=torch.float64, device="cuda")
+        g_ms = torch.tensor([res["gemv_ms_avg"]], dtype=torch.float64, device=ctl)
         dist.all_reduce(g_ms, op=dist.ReduceOp.MAX)
         gemv_ms = float(g_ms.item())
     else:

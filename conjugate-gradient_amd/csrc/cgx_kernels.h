@@ -117,8 +117,9 @@ struct MailboxView {
 // All-gather `count` doubles per rank: rank's own contribution is src; afterwards dst + q*dst_stride holds
 // rank q's for every q (own part copied from src only if copy_self).  One workgroup per peer: push my data +
 // release + flag into the peer's mailbox, wait (bounded) for the peer's flag in mine, copy its data out.
+// reduce_first: exchange the fixed-order sum of src[0..count) (one double per rank) instead of the array.
 hipError_t launch_mailbox_allgather(const MailboxView &mv, int chan, unsigned long long epoch, const double *src,
-                                    int count, double *dst, long dst_stride, int copy_self,
+                                    int count, double *dst, long dst_stride, int copy_self, int reduce_first,
                                     long long timeout_ticks, int *err, hipStream_t s);
 
 // Loopback "collective": copy local[kSlots] of every shard into gathered[] of every shard (<= 16 shards).

@@ -624,11 +624,24 @@ __global__ void k_loopback_gather(double *const *gathered_ptrs, const Scalars *c
 __global__ __launch_bounds__(256) void k_mailbox_allgather(MailboxView mv, int chan, unsigned long long epoch,
                                                             const double *__restrict__ src, int count,
                                                             double *__restrict__ dst, long dst_stride, int copy_self,
-                                                            long long timeout_ticks, int *err)
+                                                            int reduce_first, long long timeout_ticks, int *err)
 {
     const int peer = blockIdx.x;
     const int tid = threadIdx.x;
     if (*reinterpret_cast<volatile int *>(err)) return;   // an earlier wait expired: do not wait again, let the host see it
+    __shared__ double lds[4];
+    __shared__ __attribute__((aligned(16))) double s_red[2];
+    if (reduce_first) {
+        // fold my `count` values in a fixed order first and exchange ONE double (every workgroup computes the same
+        // bits): the local half of MPI_Allreduce (cg.cc:106) rides in the exchange kernel instead of a launch of its own
+        double v = 0.0;
+        for (int i = tid; i < count; i += 256) v += src[i];
+        v = block_sum<4>(v, lds);
+        if (tid == 0) { s_red[0] = v; s_red[1] = 0.0; }
+        __syncthreads();
+        src = s_red;
+        count = 1;
+    }
     if (peer == mv.rank) {
         if (copy_self)
             for (int i = tid; i < count; i += 256) dst[(long)mv.rank * dst_stride + i] = src[i];
@@ -676,9 +689,20 @@ __global__ __launch_bounds__(256) void k_mailbox_allgather(MailboxView mv, int c
         const unsigned long long *in = reinterpret_cast<const unsigned long long *>(
             mv.base[mv.rank] + mv.data_off[chan] + ((long)parity * mv.nranks + peer) * slot);
         double *out = dst + (long)peer * dst_stride;
-        for (int i = tid; i < count; i += 256)
-            out[i] = __longlong_as_double(
-                (long long)__hip_atomic_load(in + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        // 8 independent loads in flight per thread: the slot is read straight from memory, never from a cache
+        for (int base = 0; base < count; base += 8 * 256) {
+            unsigned long long v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 256 + tid;
+                v[u] = (i < count) ? __hip_atomic_load(in + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 256 + tid;
+                if (i < count) out[i] = __longlong_as_double((long long)v[u]);
+            }
+        }
     }
 }
 
@@ -869,11 +893,11 @@ hipError_t launch_scatter_coo(double *A, long lda, int row0, const int *I, const
 }
 
 hipError_t launch_mailbox_allgather(const MailboxView &mv, int chan, unsigned long long epoch, const double *src,
-                                    int count, double *dst, long dst_stride, int copy_self, long long timeout_ticks,
-                                    int *err, hipStream_t s)
+                                    int count, double *dst, long dst_stride, int copy_self, int reduce_first,
+                                    long long timeout_ticks, int *err, hipStream_t s)
 {
     hipLaunchKernelGGL(k_mailbox_allgather, dim3(mv.nranks), dim3(256), 0, s, mv, chan, epoch, src, count, dst,
-                       dst_stride, copy_self, timeout_ticks, err);
+                       dst_stride, copy_self, reduce_first, timeout_ticks, err);
     return hipGetLastError();
 }
 

@@ -306,12 +306,13 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
 
 // CGX_COMM_P2P: one lean all-gather kernel over the IPC-mapped mailboxes (cgx_kernels.hip).
 cgx_status p2p_allgather(cgx_ctx *ctx, int chan, const double *src, int count, double *dst, long dst_stride,
-                         int copy_self)
+                         int copy_self, int reduce_first = 0)
 {
     if (!ctx->p2p_ready) return fail(ctx, CGX_ERR_P2P, "cgx_p2p_import has not been called");
-    if ((long)count * 8 > ctx->mv.slot_bytes[chan]) return fail(ctx, CGX_ERR_P2P, "p2p payload larger than its slot");
+    if ((long)(reduce_first ? 1 : count) * 8 > ctx->mv.slot_bytes[chan])
+        return fail(ctx, CGX_ERR_P2P, "p2p payload larger than its slot");
     const unsigned long long epoch = ++ctx->p2p_epoch[chan];
-    HIP_TRY(ctx, cgx::launch_mailbox_allgather(ctx->mv, chan, epoch, src, count, dst, dst_stride, copy_self,
+    HIP_TRY(ctx, cgx::launch_mailbox_allgather(ctx->mv, chan, epoch, src, count, dst, dst_stride, copy_self, reduce_first,
                                                ctx->p2p_timeout_ticks, ctx->d_p2p_err, ctx->stream));
     return CGX_OK;
 }
@@ -355,7 +356,8 @@ cgx_status gather_k1_partials(cgx_ctx *ctx)
         return CGX_OK;
     case CGX_COMM_P2P: {
         Shard &s = ctx->shards[0];
-        return p2p_allgather(ctx, 0, s.k1_part, ctx->npart, s.k1_gath, ctx->npart, 1);
+        // one double per rank travels: the exchange kernel folds this rank's partials first
+        return p2p_allgather(ctx, 0, s.k1_part, ctx->npart, s.k1_gath, 1, 1, 1);
     }
     default: {
         Shard &s = ctx->shards[0];
@@ -453,7 +455,8 @@ cgx_status enqueue_iteration(cgx_ctx *ctx, int k)
     CGX_TRY(gather_k1_partials(ctx));                                                                // cg.cc:106
     for (auto &s : ctx->shards)
         HIP_TRY(ctx, cgx::launch_update_xr(s.rows, s.p[(k + 1) & 1] + s.row0, s.Ap, s.x, s.seg, s.sc, k & 1, s.k1_gath,
-                                           ctx->nranks * ctx->npart, s.partials, st));               // cg.cc:105-116
+                                           ctx->cfg.comm_mode == CGX_COMM_P2P ? ctx->nranks : ctx->nranks * ctx->npart,
+                                           s.partials, st));                                         // cg.cc:105-116
     CGX_TRY(gather_segments(ctx));                                                                   // cg.cc:117,135-136
     return CGX_OK;
 }
