@@ -48,6 +48,8 @@ public:
     int psize() const { return m_cfg.nranks; }
     /// print the reference's DEBUG line (cg.cc:152-153) after solve; default true on rank 0
     void set_verbose(bool v) { m_verbose = v; }
+    /// the underlying C-ABI context (for the CGX_COMM_P2P wire-up: cgx_p2p_export / import / selftest)
+    cgx_ctx *context() const { return m_ctx; }
 
 private:
     void check(int status, const char *what) const;

@@ -5,8 +5,9 @@
 //
 // If argv[1] parses completely as an integer it is the generator form, otherwise a Matrix-Market path.
 // Where the reference took its process count from `srun -n P`, this takes `--gpus P` (or CG_NGPU):
-// the binary forks P-1 children BEFORE touching the GPU, one process per MI355X, and the ranks meet
-// through an RCCL unique id passed over pipes (replaces MPI_Init, cg_main.cc:15-20).
+// the binary forks P-1 children BEFORE touching the GPU, one process per MI355X, and the ranks meet over
+// pipes (replaces MPI_Init, cg_main.cc:15-20): mailbox IPC handles for the direct-xGMI exchange, or an
+// RCCL unique id.
 // `--loopback P` runs P logical row blocks on one GPU (CI stand-in for a multi-GPU node).
 #include <sys/wait.h>
 #include <unistd.h>
@@ -16,6 +17,7 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <memory>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -41,7 +43,8 @@ int usage(const char *prog)
 {
     std::cerr << "Usage: " << prog << " N OUTFILE [MAXITER]            (generated matrix of size N)\n"
               << "       " << prog << " FILE.mtx NUM_THREADS BLOCK_WIDTH true|false OUTFILE\n"
-              << "options: --gpus P (or CG_NGPU=P)  one process per MI355X, RCCL over xGMI\n"
+              << "options: --gpus P (or CG_NGPU=P)  one process per MI355X\n"
+              << "         --transport auto|p2p|rccl  exchange: direct xGMI mailboxes, RCCL, or p2p with RCCL fallback\n"
               << "         --loopback P             P logical row blocks on one GPU\n"
               << "         --stats                  also print iterations/s and K1 GB/s on stderr" << std::endl;
     return 1;
@@ -54,13 +57,16 @@ int main(int argc, char **argv)
     // ---- split options from the reference's positional arguments -------------------------------------
     std::vector<std::string> pos;
     int ngpu = 1, loopback = 0;
-    bool stats = false;
+    bool stats = false, same_device = false;
+    std::string transport = "auto";
     if (const char *e = getenv("CG_NGPU")) ngpu = atoi(e);
     for (int i = 1; i < argc; ++i) {
         std::string a(argv[i]);
         if (a == "--gpus" && i + 1 < argc) ngpu = atoi(argv[++i]);
         else if (a == "--loopback" && i + 1 < argc) loopback = atoi(argv[++i]);
         else if (a == "--stats") stats = true;
+        else if (a == "--transport" && i + 1 < argc) transport = argv[++i];
+        else if (a == "--same-device") same_device = true;   // rehearsal: every rank on device 0 (p2p only)
         else pos.push_back(a);
     }
     if (pos.empty()) return usage(argv[0]);   // cg_main.cc:22-26 (returns 1)
@@ -86,64 +92,136 @@ int main(int argc, char **argv)
     }
 
     // ---- one process per GPU: fork before any HIP/RCCL call -------------------------------------------
+    // Rank 0 is the hub of a tiny control plane over pipes (what MPI_Init gave the reference): all-gather of a
+    // few bytes and an all-min of one int, used to pass the RCCL id / the mailbox IPC handles around.
     int rank = 0;
-    std::vector<int> wr_pipes;
-    int rd_pipe = -1;
+    std::vector<int> up_rd, down_wr;   // rank 0: one pair per child
+    int up_wr = -1, down_rd = -1;      // child: its own pair
     std::vector<pid_t> kids;
     if (ngpu > 1) {
         for (int r = 1; r < ngpu; ++r) {
-            int fd[2];
-            if (pipe(fd) != 0) { perror("pipe"); return 1; }
+            int up[2], down[2];
+            if (pipe(up) != 0 || pipe(down) != 0) { perror("pipe"); return 1; }
             pid_t pid = fork();
             if (pid < 0) { perror("fork"); return 1; }
             if (pid == 0) {
                 rank = r;
-                rd_pipe = fd[0];
-                close(fd[1]);
-                for (int w : wr_pipes) close(w);
-                wr_pipes.clear();
+                up_wr = up[1];
+                down_rd = down[0];
+                close(up[0]);
+                close(down[1]);
+                for (int f : up_rd) close(f);
+                for (int f : down_wr) close(f);
+                up_rd.clear();
+                down_wr.clear();
                 kids.clear();
                 break;
             }
             kids.push_back(pid);
-            wr_pipes.push_back(fd[1]);
-            close(fd[0]);
+            up_rd.push_back(up[0]);
+            down_wr.push_back(down[1]);
+            close(up[1]);
+            close(down[0]);
         }
     }
+    auto write_all = [](int fd, const void *buf, size_t n) {
+        const char *p = static_cast<const char *>(buf);
+        while (n) {
+            ssize_t k = write(fd, p, n);
+            if (k <= 0) throw std::runtime_error("control pipe write failed");
+            p += k;
+            n -= static_cast<size_t>(k);
+        }
+    };
+    auto read_all = [](int fd, void *buf, size_t n) {
+        char *p = static_cast<char *>(buf);
+        while (n) {
+            ssize_t k = read(fd, p, n);
+            if (k <= 0) throw std::runtime_error("control pipe closed (a rank died)");
+            p += k;
+            n -= static_cast<size_t>(k);
+        }
+    };
+    // every rank contributes `n` bytes; every rank receives all ngpu contributions in rank order
+    auto allgather_bytes = [&](const unsigned char *mine, size_t n) {
+        std::vector<unsigned char> all(static_cast<size_t>(ngpu) * n);
+        if (ngpu == 1) {
+            memcpy(all.data(), mine, n);
+        } else if (rank == 0) {
+            memcpy(all.data(), mine, n);
+            for (int r = 1; r < ngpu; ++r) read_all(up_rd[r - 1], all.data() + static_cast<size_t>(r) * n, n);
+            for (int r = 1; r < ngpu; ++r) write_all(down_wr[r - 1], all.data(), all.size());
+        } else {
+            write_all(up_wr, mine, n);
+            read_all(down_rd, all.data(), all.size());
+        }
+        return all;
+    };
+    auto all_min = [&](int v) {
+        unsigned char b = static_cast<unsigned char>(v ? 1 : 0);
+        std::vector<unsigned char> all = allgather_bytes(&b, 1);
+        for (unsigned char x : all)
+            if (!x) return 0;
+        return 1;
+    };
 
     int rc = 0;
     try {
         cgx_config cfg;
         cgx_config_init(&cfg);
+        cfg.profile_gemv = stats ? 1 : 0;
+        std::unique_ptr<CGSolver> holder;
         if (ngpu > 1) {
-            cfg.comm_mode = CGX_COMM_RCCL;
             cfg.nranks = ngpu;
             cfg.rank = rank;
-            cfg.device = rank;
-            if (rank == 0) {
-                if (cgx_comm_unique_id(cfg.unique_id) != CGX_OK)
-                    throw std::runtime_error(std::string("cgx_comm_unique_id: ") + cgx_last_error(nullptr));
-                for (int w : wr_pipes) {
-                    if (write(w, cfg.unique_id, CGX_UNIQUE_ID_BYTES) != CGX_UNIQUE_ID_BYTES) throw std::runtime_error("pipe write");
-                    close(w);
+            cfg.device = same_device ? 0 : rank;
+            bool have = false;
+            if (transport != "rccl") {
+                // direct-xGMI mailboxes: create, exchange IPC handles, self-test; all ranks agree on the outcome
+                cfg.comm_mode = CGX_COMM_P2P;
+                int ok = 1;
+                unsigned char handle[CGX_IPC_HANDLE_BYTES] = {0};
+                try {
+                    holder.reset(new CGSolver(cfg));
+                    if (cgx_p2p_export(holder->context(), handle) != CGX_OK) ok = 0;
+                } catch (const std::exception &e) {
+                    std::cerr << "cgsolver (rank " << rank << "): p2p unavailable: " << e.what() << std::endl;
+                    ok = 0;
                 }
-            } else {
-                size_t got = 0;
-                while (got < CGX_UNIQUE_ID_BYTES) {
-                    ssize_t k = read(rd_pipe, cfg.unique_id + got, CGX_UNIQUE_ID_BYTES - got);
-                    if (k <= 0) throw std::runtime_error("rank 0 went away before sending the RCCL id");
-                    got += static_cast<size_t>(k);
+                std::vector<unsigned char> all = allgather_bytes(handle, CGX_IPC_HANDLE_BYTES);
+                if (all_min(ok)) {
+                    int st_ok = 0;
+                    if (cgx_p2p_import(holder->context(), all.data()) != CGX_OK) ok = 0;
+                    if (all_min(ok)) {
+                        if (cgx_p2p_selftest(holder->context(), 32, &st_ok) != CGX_OK) st_ok = 0;
+                        have = all_min(st_ok) != 0;
+                    }
                 }
-                close(rd_pipe);
+                if (!have) {
+                    holder.reset();
+                    if (transport == "p2p") throw std::runtime_error("--transport p2p: mailboxes unavailable or self-test failed");
+                    if (rank == 0) std::cerr << "cgsolver: direct peer exchange unavailable, using RCCL" << std::endl;
+                }
             }
-        } else if (loopback > 1) {
-            cfg.comm_mode = CGX_COMM_LOOPBACK;
-            cfg.nranks = loopback;
+            if (!have) {
+                cfg.comm_mode = CGX_COMM_RCCL;
+                unsigned char uid[CGX_UNIQUE_ID_BYTES] = {0};
+                if (rank == 0 && cgx_comm_unique_id(uid) != CGX_OK)
+                    throw std::runtime_error(std::string("cgx_comm_unique_id: ") + cgx_last_error(nullptr));
+                std::vector<unsigned char> all = allgather_bytes(uid, CGX_UNIQUE_ID_BYTES);
+                memcpy(cfg.unique_id, all.data(), CGX_UNIQUE_ID_BYTES);   // rank 0's id
+                holder.reset(new CGSolver(cfg));
+            }
+        } else {
+            if (loopback > 1) {
+                cfg.comm_mode = CGX_COMM_LOOPBACK;
+                cfg.nranks = loopback;
+            }
+            holder.reset(new CGSolver(cfg));
         }
-        cfg.profile_gemv = stats ? 1 : 0;
         const int psize = cfg.nranks;
+        CGSolver &solver = *holder;
 
-        CGSolver solver(cfg);
         if (gen_form) solver.generate_lap2d_matrix(gen_n);   // cg_main.cc:31
         else solver.read_matrix(pos[0]);                     // code/CUDA/cg_main.cc:37
         const int n = solver.n();

@@ -32,3 +32,17 @@ def test_p2p_processes_on_one_gpu(tmp_path, world, n, max_iter, port):
     assert v["dx"] < 1e-12, v
     if not v["converged"]:
         assert v["residual_rel"] < 1e-6, v
+
+
+def test_cgsolver_cli_forked_ranks_over_mailboxes(tmp_path):
+    """`cgsolver N OUT MAXITER --gpus 3`: the CLI forks one process per rank before touching the GPU and wires
+    the mailboxes over pipes.  --same-device puts every rank on device 0 (one-GPU rehearsal)."""
+    exe = os.path.join(ROOT, "conjugate-gradient_amd", "cgsolver")
+    out = tmp_path / "strong.txt"
+    r = subprocess.run([exe, "2048", str(out), "200", "--gpus", "3", "--same-device", "--transport", "p2p", "--stats"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "[STEP 200] residual = 1.331819e-05, ||x|| = 8.808702e+07" in r.stdout      # reference's own numbers (SURVEY section 4)
+    assert r.stdout.count("[STEP") == 1                                                 # only rank 0 prints (cg.cc:144)
+    assert out.read_text().strip().startswith("2048,3,")
+    assert "gpus=3" in r.stderr
