@@ -210,8 +210,22 @@ long default_lda(const cgx_ctx *ctx, int n)
 cgx_status setup_problem(cgx_ctx *ctx, int n)
 {
     if (n <= 0) return fail(ctx, CGX_ERR_BAD_ARG, "matrix size must be positive");
-    free_problem(ctx);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->shards.empty() && ctx->n == n && ctx->lda == default_lda(ctx, n)) {
+        // Same geometry as the current problem: keep every buffer.  (Freeing and re-allocating a multi-GiB matrix
+        // can land on fragmented memory and cost ~3 % of K1; measured in bench.py's transport calibration.)
+        ctx->max_iter = n;
+        ctx->have_matrix = ctx->have_b = false;
+        ctx->in_solve = false;
+        for (auto &s : ctx->shards) {
+            HIP_TRY(ctx, hipMemsetAsync(s.p[0], 0, (size_t)ctx->lda * sizeof(double), ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(s.p[1], 0, (size_t)ctx->lda * sizeof(double), ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(s.sc, 0, sizeof(Scalars), ctx->stream));
+        }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return CGX_OK;
+    }
+    free_problem(ctx);
     ctx->m = ctx->n = n;
     ctx->max_iter = n;   // m_maxIter = size, code/MPI/cg.cc:172
     ctx->lda = default_lda(ctx, n);
