@@ -43,6 +43,7 @@ int usage(const char *prog)
 {
     std::cerr << "Usage: " << prog << " N OUTFILE [MAXITER]            (generated matrix of size N)\n"
               << "       " << prog << " FILE.mtx NUM_THREADS BLOCK_WIDTH true|false OUTFILE\n"
+              << "       " << prog << " FILE.mtx OUTFILE [MAXITER]       (matrix file, MPI-form output)\n"
               << "options: --gpus P (or CG_NGPU=P)  one process per MI355X\n"
               << "         --transport auto|p2p|rccl  exchange: direct xGMI mailboxes, RCCL, or p2p with RCCL fallback\n"
               << "         --loopback P             P logical row blocks on one GPU\n"
@@ -76,7 +77,7 @@ int main(int argc, char **argv)
     const bool gen_form = parse_int(pos[0], &gen_n);
     std::string out_file;
     int max_iter = -1, legacy_nt = 0, legacy_bw = 0;
-    bool legacy_t = false;
+    bool legacy_t = false, cuda_form = false;
     if (gen_form) {
         if (pos.size() < 2) return usage(argv[0]);
         out_file = pos[1];
@@ -84,11 +85,21 @@ int main(int argc, char **argv)
             std::stringstream ss(pos[2]);
             ss >> max_iter;
         }
-    } else {
-        if (pos.size() < 5) return usage(argv[0]);   // the reference reads argv[2..5] unguarded (cg_main.cc:21-33)
+    } else if (pos.size() >= 5) {
+        // CUDA form; the reference reads argv[2..5] unguarded (code/CUDA/cg_main.cc:21-33)
         if (!parse_int(pos[1], &legacy_nt) || !parse_int(pos[2], &legacy_bw)) return usage(argv[0]);
         legacy_t = (pos[3] == "true");
         out_file = pos[4];
+        cuda_form = true;
+    } else {
+        // MPI form with a matrix file: `cgsolver FILE.mtx OUTFILE [MAXITER]`.  The reference's MPI read_matrix
+        // never sets the sizes (cg.cc:191-202), so it could not do this; the CSV line is the MPI one.
+        if (pos.size() < 2) return usage(argv[0]);
+        out_file = pos[1];
+        if (pos.size() >= 3) {
+            std::stringstream ss(pos[2]);
+            ss >> max_iter;
+        }
     }
 
     // ---- one process per GPU: fork before any HIP/RCCL call -------------------------------------------
@@ -231,13 +242,13 @@ int main(int argc, char **argv)
         std::vector<double> x_d(static_cast<size_t>(n), 0.);   // cg_main.cc:49-50
 
         auto t1 = clk::now();                                // only solve() is timed, cg_main.cc:53-55
-        if (gen_form) solver.solve(x_d);
-        else solver.solve(x_d.data(), legacy_nt, legacy_bw, legacy_t);
+        if (cuda_form) solver.solve(x_d.data(), legacy_nt, legacy_bw, legacy_t);
+        else solver.solve(x_d);
         second elapsed = clk::now() - t1;
 
         if (rank == 0) {
             std::ofstream outfile(out_file.c_str(), std::ios_base::app);
-            if (gen_form) {
+            if (!cuda_form) {
                 outfile << n << "," << psize << "," << elapsed.count() << std::endl;   // cg_main.cc:62
             } else {
                 std::cout << "Time for CG (dense solver)  = " << elapsed.count() << " [s]\n";   // code/CUDA/cg_main.cc:54

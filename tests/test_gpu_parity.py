@@ -326,3 +326,9 @@ def test_cgsolver_cli_both_forms(gpu_pkg, mtx_path, tmp_path):
     assert "Time for CG (dense solver)  = " in r.stdout and "||x|| = 2.147364e+09" in r.stdout
     nt, bw, secs = out2.read_text().strip().split(",")
     assert (nt, bw) == ("1024", "16") and float(secs) > 0
+    # matrix file with the MPI form's arguments and CSV (the reference's MPI read_matrix could not: cg.cc:191-202)
+    out3 = tmp_path / "mtx_mpi.txt"
+    r = subprocess.run([exe, mtx_path, str(out3), "100", "--loopback", "2"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.startswith("\t[STEP 100] residual = ")
+    assert out3.read_text().strip().startswith("10000,2,")
