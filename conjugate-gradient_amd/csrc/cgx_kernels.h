@@ -25,9 +25,10 @@ struct Scalars {
     unsigned counter[2];   // arrival tickets of the in-kernel reductions of K1 / K3 (always 0 between launches)
 };
 
-// The exchanged residual: P equal segments of S doubles, segment q = [ r slice of rank q (Sr doubles,
-// zero padded) | kSlots scalars of rank q ].  One in-place all-gather of S doubles per rank moves r AND
-// r.r together (MPI_Allgatherv + MPI_Allreduce of cg.cc:117,135-136 in one message).
+// Segmented vector: P equal segments of S doubles, segment q = [ slice of rank q (Sr doubles, zero padded) |
+// tail ].  Used for the exchanged Ap ([Ap slice | p.Ap partials], one in-place all-gather per iteration in
+// place of MPI_Allreduce cg.cc:106 + MPI_Allgatherv cg.cc:135-136) and, with nranks = 1, for the replicated
+// r ([r (lda) | scalars]).
 struct SegView {
     double *base;     // this shard's copy of all P segments
     int S, Sr;        // segment stride, r part
@@ -67,12 +68,11 @@ hipError_t launch_gemv_fused(const GemvPlan &plan, const double *A, long lda, in
                              const double *p_old, double *p_new, SegView seg, double *Ap, double *partials,
                              Scalars *sc, int k, double tol, hipStream_t s);
 
-// K3: conj = fixed-order sum of gathered[0..ngathered) (all ranks' K1 partials); alpha = rsold / max(conj,
-// rsold*1e-14); x += alpha p; r -= alpha Ap (r lives in this shard's segment); segment scalar slot kSlotRr =
-// sum r_i^2 (in-kernel reduction by the last-arriving workgroup).  cg.cc:105-116.
-hipError_t launch_update_xr(int count, const double *p_local, const double *Ap, double *x, SegView seg,
-                            Scalars *sc, int parity, const double *gathered, int ngathered, double *partials,
-                            hipStream_t s);
+// K3: p.Ap = fixed-order sum over all ranks q of the tail_count doubles at tail_off of segment q's tail;
+// alpha = rsold / max(p.Ap, rsold*1e-14); x_sub += alpha p_sub (own rows); r -= alpha Ap for ALL n rows (r is
+// replicated, rv = [r (lda) | scalars]); scalar slot kSlotRr of rv = sum r_i^2 (last-arriving workgroup).  cg.cc:105-116.
+hipError_t launch_update_xr(int n, int rows, int row0, const double *p_new, SegView apv, int tail_off, int tail_count,
+                            double *x, SegView rv, Scalars *sc, int parity, double *partials, hipStream_t s);
 int update_xr_grid(int count);
 
 // Tail of the LAST executed iteration when the loop runs out (k = number of iterations done):
@@ -83,9 +83,8 @@ hipError_t launch_close_iteration(Scalars *sc, SegView seg, int k, double tol, h
 hipError_t launch_reduce_partials(const double *partials, int n, double *out, hipStream_t s);
 hipError_t launch_reduce_partials3(const double *partials, int n, double *out3, hipStream_t s);
 
-// Initial residual (cg.cc:79-85): r = b - Ap into this shard's segment; partials[wg] = sum r_i^2.
-hipError_t launch_init_residual(int count, const double *b, const double *Ap, SegView seg, double *partials,
-                                hipStream_t s);
+// Initial residual (cg.cc:79-85): r = b - Ap for all n rows (Ap from the gathered segments); partials[wg] = sum r_i^2.
+hipError_t launch_init_residual(int n, const double *b_full, SegView apv, SegView rv, double *partials, hipStream_t s);
 
 // v_full[c] = segment value of column c (c < n), 0 for the pad: turns gathered slices into a replicated vector.
 hipError_t launch_unpack_segments(SegView seg, double *v_full, long lda, hipStream_t s);
@@ -105,7 +104,7 @@ hipError_t launch_scatter_coo(double *A, long lda, int row0, const int *I, const
 // Every rank owns one fine-grained mailbox; all ranks map all mailboxes.  Layout (identical on every rank):
 //   flags : [kP2pChannels][kMaxRanks] words, one 128-B line each   (flag[c][q] = last epoch rank q delivered on channel c)
 //   data  : per channel c, [2 parities][nranks] slots of slot_bytes[c]
-constexpr int kP2pChannels = 3;          // 0 = K1 partials, 1 = [r | r.r] segments, 2 = DEBUG scalars
+constexpr int kP2pChannels = 3;          // 0 = unused, 1 = [Ap slice | p.Ap] segments, 2 = DEBUG scalars
 constexpr int kP2pFlagStride = 128;      // bytes between flag words
 struct MailboxView {
     unsigned char *base[kMaxRanks];      // base[q] = rank q's mailbox as mapped in THIS process (base[rank] = own)
@@ -115,12 +114,13 @@ struct MailboxView {
 };
 
 // All-gather `count` doubles per rank: rank's own contribution is src; afterwards dst + q*dst_stride holds
-// rank q's for every q (own part copied from src only if copy_self).  One workgroup per peer: push my data +
-// release + flag into the peer's mailbox, wait (bounded) for the peer's flag in mine, copy its data out.
-// reduce_first: exchange the fixed-order sum of src[0..count) (one double per rank) instead of the array.
+// rank q's for every q (own part copied from src only if copy_self).  If tail_n > 0, the fixed-order sum of
+// src[tail_off .. tail_off+tail_n) travels as one extra double and lands at dst[q*dst_stride + sum_off].
+// One workgroup per peer: push my data + release + flag into the peer's mailbox, wait (bounded) for the peer's
+// flag in mine, copy its data out.
 hipError_t launch_mailbox_allgather(const MailboxView &mv, int chan, unsigned long long epoch, const double *src,
-                                    int count, double *dst, long dst_stride, int copy_self, int reduce_first,
-                                    long long timeout_ticks, int *err, hipStream_t s);
+                                    int count, int tail_off, int tail_n, double *dst, long dst_stride, int sum_off,
+                                    int copy_self, long long timeout_ticks, int *err, hipStream_t s);
 
 // Loopback "collective": copy local[kSlots] of every shard into gathered[] of every shard (<= 16 shards).
 hipError_t launch_loopback_gather(double *const *gathered_ptrs, const Scalars *const *scalar_ptrs, int nshards,

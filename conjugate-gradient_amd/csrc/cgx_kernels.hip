@@ -1,23 +1,26 @@
 // cgx_kernels.hip -- hand-written CDNA4 (gfx950, wave64) kernels of the dense fp64 CG hot path.
 //
 // The path restated here is CGSolver::solve's loop body, code/MPI/cg.cc:96-137 (reference file:line).
-// One iteration k is TWO kernels and TWO exchanges:
+// One iteration k is TWO kernels and ONE exchange:
 //
-//   K1 gemv_fused   tail of iteration k-1:  rsnew = allreduce(r.r)              cg.cc:117
+//   K1 gemv_fused   tail of iteration k-1:  rsnew = r.r                          cg.cc:116-117
 //                                           if sqrt(rsnew) < tol: break          cg.cc:120-121
 //                                           beta = rsnew/rsold                   cg.cc:124
 //                                           p = r + beta p   (on the fly)        cg.cc:127-129
 //                                           rsold = rsnew                        cg.cc:132
-//                   head of iteration k:    Ap = A_sub p                         cg.cc:100-102 (cblas_dgemv)
-//                                           local p_sub.Ap_sub                   cg.cc:105     (cblas_ddot)
-//   -- exchange 1: all-gather of kSlots doubles (the p.Ap partials)              cg.cc:106     (MPI_Allreduce)
-//   K3 update_xr    alpha                                                        cg.cc:107
-//                   x += alpha p ; r -= alpha Ap ; local r.r                     cg.cc:110,113,116
-//   -- exchange 2: all-gather of [r slice | r.r partial]                         cg.cc:117 + 135-136
+//                   head of iteration k:    Ap_sub = A_sub p                     cg.cc:100-102 (cblas_dgemv)
+//                                           partials of p_sub.Ap_sub             cg.cc:105     (cblas_ddot)
+//   -- exchange: all-gather of [Ap slice | p.Ap partials]                        cg.cc:106 (MPI_Allreduce) + 135-136
+//   K3 update_xr    p.Ap = fixed-order sum of all ranks' partials; alpha         cg.cc:107
+//                   x_sub += alpha p_sub                                         cg.cc:110
+//                   r -= alpha Ap for ALL n rows (r is replicated); r.r          cg.cc:113,116
 //
-// Fusing the p update into the GEMV means the vector that travels between ranks is r, not p: every rank
-// recomputes p = r + beta p for all N columns while it streams them for the GEMV anyway (bitwise the
-// same value everywhere), so the reference's third collective and its separate update kernel disappear.
+// What travels between ranks is Ap, not p: r and p are replicated, every rank updates the whole r from the
+// gathered Ap and reduces r.r over all n rows in the same fixed order, so r.r is bit-identical on every
+// rank WITHOUT a second all-reduce, and p = r + beta p is formed by every rank inside the next K1 while it
+// streams the columns anyway.  The reference's 2 all-reduces + 1 all-gather per iteration become one
+// exchange; the arithmetic per element is the reference's (same formulas, fma), only the summation order of
+// the dot products differs, which the reference does not fix either (OpenBLAS/MPI reduction order).
 // None of this is derived from code/CUDA/cg.cu (thread-per-row-chunk kernels with atomicAdd); these are
 // streaming kernels without floating-point atomics, deterministic for a fixed launch shape.
 //
@@ -94,7 +97,7 @@ __device__ __forceinline__ void grid_sum_last_arriver(double d /* thread 0 */, d
     }
 }
 
-enum { kPlain = 0, kFusedSingle = 1, kFusedMulti = 2 };
+enum { kPlain = 0, kFusedSingle = 1 };   // the fused form always reads the replicated, contiguous r
 
 template <bool NT>
 __device__ __forceinline__ d2 load_a(const double *ptr)
@@ -455,35 +458,42 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_ldsp(const double *__restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// K3: x += alpha p ; r -= alpha Ap ; r.r          (cg.cc:107-116)
-// r is this shard's slice inside the exchange segment; r.r lands in the segment's scalar slot.
+// K3: x_sub += alpha p_sub ; r -= alpha Ap (all n rows) ; r.r          (cg.cc:106-116)
+// apv: the gathered segments [Ap slice | tail] of all ranks; the p.Ap partials of rank q are the
+// tail_count doubles at tail_off of its segment.  rv: the replicated r, [r (lda) | scalars].
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_update_xr(int count, const double *__restrict__ p_local,
-                                                    const double *__restrict__ Ap, double *__restrict__ x,
-                                                    SegView sv, Scalars *sc, int parity,
-                                                    const double *__restrict__ gathered, int ngathered, double *partials)
+__global__ __launch_bounds__(256) void k_update_xr(int n, int rows, int row0, const double *__restrict__ p_new,
+                                                    SegView apv, int tail_off, int tail_count,
+                                                    double *__restrict__ x, SegView rv, Scalars *sc, int parity,
+                                                    double *partials)
 {
     if (sc->done) return;
     __shared__ double lds[4];
     __shared__ int s_flag;
-    double *r = sv.base + (long)sv.rank * sv.S;
+    double *r = rv.base;
     const double rsold = sc->rs[parity];
     // p.Ap = sum of every K1 workgroup partial of every rank (cblas_ddot + MPI_Allreduce, cg.cc:105-106), folded
     // in one fixed order by every workgroup of every rank: bit-identical everywhere.
     double cs = 0.0;
-    for (int i = threadIdx.x; i < ngathered; i += 256) cs += gathered[i];
+    const int total = apv.nranks * tail_count;
+    for (int i = threadIdx.x; i < total; i += 256) {
+        const int q = i / tail_count, j = i - q * tail_count;
+        cs += apv.base[(long)q * apv.S + apv.Sr + tail_off + j];
+    }
     const double conj = block_sum<4>(cs, lds);
     const double alpha = rsold / fmax(conj, rsold * kNearZero);      // cg.cc:107
-    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int i = blockIdx.x * 256 + threadIdx.x;                     // global row
     double rr = 0.0;
-    if (i < count) {
-        x[i] = fma(alpha, p_local[i], x[i]);                          // cg.cc:110
-        const double rn = fma(-alpha, Ap[i], r[i]);                   // cg.cc:113
+    if (i < n) {
+        const double apv_i = seg_load(apv, i);
+        const double rn = fma(-alpha, apv_i, r[i]);                   // cg.cc:113, for every row (r is replicated)
         r[i] = rn;
         rr = rn * rn;                                                 // cg.cc:116
+        const int li = i - row0;
+        if (li >= 0 && li < rows) x[li] = fma(alpha, p_new[i], x[li]);   // cg.cc:110, own rows only
     }
     rr = block_sum<4>(rr, lds);
-    grid_sum_last_arriver<4>(rr, partials, &sc->counter[1], r + sv.Sr + kSlotRr, lds, &s_flag);
+    grid_sum_last_arriver<4>(rr, partials, &sc->counter[1], r + rv.Sr + kSlotRr, lds, &s_flag);
 }
 
 // Loop ran out after k iterations: the tail of iteration k-1 that the next K1 would have done.
@@ -515,18 +525,17 @@ __global__ __launch_bounds__(256) void k_reduce_partials(const double *__restric
 // ------------------------------------------------------------------------------------------------
 // setup / verification kernels (outside the iteration loop)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_init_residual(int count, const double *__restrict__ b,
-                                                        const double *__restrict__ Ap, SegView sv,
-                                                        double *__restrict__ partials)
+__global__ __launch_bounds__(256) void k_init_residual(int n, const double *__restrict__ b_full, SegView apv,
+                                                        SegView rv, double *__restrict__ partials)
 {
     __shared__ double lds[4];
-    double *r = sv.base + (long)sv.rank * sv.S;
+    double *r = rv.base;
     const int i = blockIdx.x * 256 + threadIdx.x;
     double rr = 0.0;
-    if (i < count) {
-        const double rv = b[i] - Ap[i];        // r_sub = b_sub - A_sub x, cg.cc:79-82
-        r[i] = rv;
-        rr = rv * rv;                          // rsold = r.p with p == r, cg.cc:85,91
+    if (i < n) {
+        const double rvv = b_full[i] - seg_load(apv, i);   // r = b - A x, cg.cc:79-82 (all rows: r is replicated)
+        r[i] = rvv;
+        rr = rvv * rvv;                                    // rsold = r.p with p == r, cg.cc:85,91
     }
     rr = block_sum<4>(rr, lds);
     if (threadIdx.x == 0) partials[blockIdx.x] = rr;
@@ -622,34 +631,31 @@ __global__ void k_loopback_gather(double *const *gathered_ptrs, const Scalars *c
 // after the kernel that consumed epoch e on that peer has finished (stream order).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_mailbox_allgather(MailboxView mv, int chan, unsigned long long epoch,
-                                                            const double *__restrict__ src, int count,
-                                                            double *__restrict__ dst, long dst_stride, int copy_self,
-                                                            int reduce_first, long long timeout_ticks, int *err)
+                                                            const double *__restrict__ src, int count, int tail_off,
+                                                            int tail_n, double *__restrict__ dst, long dst_stride,
+                                                            int sum_off, int copy_self, long long timeout_ticks, int *err)
 {
     const int peer = blockIdx.x;
     const int tid = threadIdx.x;
     if (*reinterpret_cast<volatile int *>(err)) return;   // an earlier wait expired: do not wait again, let the host see it
     __shared__ double lds[4];
-    __shared__ __attribute__((aligned(16))) double s_red[2];
-    if (reduce_first) {
-        // fold my `count` values in a fixed order first and exchange ONE double (every workgroup computes the same
-        // bits): the local half of MPI_Allreduce (cg.cc:106) rides in the exchange kernel instead of a launch of its own
+    double tail_sum = 0.0;
+    if (tail_n > 0) {
+        // fold my tail (the K1 partials) in a fixed order and ship ONE double behind the main payload (every
+        // workgroup computes the same bits): the local half of MPI_Allreduce (cg.cc:106) rides in the exchange
         double v = 0.0;
-        for (int i = tid; i < count; i += 256) v += src[i];
-        v = block_sum<4>(v, lds);
-        if (tid == 0) { s_red[0] = v; s_red[1] = 0.0; }
-        __syncthreads();
-        src = s_red;
-        count = 1;
+        for (int i = tid; i < tail_n; i += 256) v += src[tail_off + i];
+        tail_sum = block_sum<4>(v, lds);
     }
     if (peer == mv.rank) {
         if (copy_self)
             for (int i = tid; i < count; i += 256) dst[(long)mv.rank * dst_stride + i] = src[i];
+        if (tail_n > 0 && tid == 0) dst[(long)mv.rank * dst_stride + sum_off] = tail_sum;
         return;
     }
     const int parity = (int)(epoch & 1);
     const long slot = mv.slot_bytes[chan];
-    // ---- push my contribution into the peer's mailbox --------------------------------------------------
+    // ---- push my contribution into the peer's mailbox: [count doubles | tail sum] ----------------------------
     {
         double *out = reinterpret_cast<double *>(mv.base[peer] + mv.data_off[chan] +
                                                  ((long)parity * mv.nranks + mv.rank) * slot);
@@ -657,6 +663,7 @@ __global__ __launch_bounds__(256) void k_mailbox_allgather(MailboxView mv, int c
         for (int i = tid; i < pairs; i += 256)
             *reinterpret_cast<d2 *>(out + 2 * i) = *reinterpret_cast<const d2 *>(src + 2 * i);
         if ((count & 1) && tid == 0) out[count - 1] = src[count - 1];
+        if (tail_n > 0 && tid == 0) out[count] = tail_sum;
         __threadfence_system();   // release: my stores are visible system-wide before the flag below
         __syncthreads();
         if (tid == 0) {
@@ -689,18 +696,20 @@ __global__ __launch_bounds__(256) void k_mailbox_allgather(MailboxView mv, int c
         const unsigned long long *in = reinterpret_cast<const unsigned long long *>(
             mv.base[mv.rank] + mv.data_off[chan] + ((long)parity * mv.nranks + peer) * slot);
         double *out = dst + (long)peer * dst_stride;
+        const int total = count + (tail_n > 0 ? 1 : 0);
         // 8 independent loads in flight per thread: the slot is read straight from memory, never from a cache
-        for (int base = 0; base < count; base += 8 * 256) {
+        for (int base = 0; base < total; base += 8 * 256) {
             unsigned long long v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = base + u * 256 + tid;
-                v[u] = (i < count) ? __hip_atomic_load(in + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
+                v[u] = (i < total) ? __hip_atomic_load(in + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0ull;
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = base + u * 256 + tid;
                 if (i < count) out[i] = __longlong_as_double((long long)v[u]);
+                else if (i == count && tail_n > 0) out[sum_off] = __longlong_as_double((long long)v[u]);
             }
         }
     }
@@ -820,16 +829,16 @@ hipError_t launch_gemv_fused(const GemvPlan &pl, const double *A, long lda, int 
                              hipStream_t s)
 {
     GemvArgs g{A, lda, rows, row0, p_old, p_new, seg, Ap, partials, sc, k, tol};
-    return seg.nranks == 1 ? dispatch_gemv<kFusedSingle>(pl, g, s) : dispatch_gemv<kFusedMulti>(pl, g, s);
+    return dispatch_gemv<kFusedSingle>(pl, g, s);
 }
 
 int update_xr_grid(int count) { return count > 0 ? ceil_div(count, 256) : 1; }
 
-hipError_t launch_update_xr(int count, const double *p_local, const double *Ap, double *x, SegView seg, Scalars *sc,
-                            int parity, const double *gathered, int ngathered, double *partials, hipStream_t s)
+hipError_t launch_update_xr(int n, int rows, int row0, const double *p_new, SegView apv, int tail_off, int tail_count,
+                            double *x, SegView rv, Scalars *sc, int parity, double *partials, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_update_xr, dim3(update_xr_grid(count)), dim3(256), 0, s, count, p_local, Ap, x, seg, sc, parity,
-                       gathered, ngathered, partials);
+    hipLaunchKernelGGL(k_update_xr, dim3(update_xr_grid(n)), dim3(256), 0, s, n, rows, row0, p_new, apv, tail_off,
+                       tail_count, x, rv, sc, parity, partials);
     return hipGetLastError();
 }
 
@@ -851,10 +860,9 @@ hipError_t launch_reduce_partials3(const double *partials, int n, double *out3, 
     return hipGetLastError();
 }
 
-hipError_t launch_init_residual(int count, const double *b, const double *Ap, SegView seg, double *partials,
-                                hipStream_t s)
+hipError_t launch_init_residual(int n, const double *b_full, SegView apv, SegView rv, double *partials, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_init_residual, dim3(update_xr_grid(count)), dim3(256), 0, s, count, b, Ap, seg, partials);
+    hipLaunchKernelGGL(k_init_residual, dim3(update_xr_grid(n)), dim3(256), 0, s, n, b_full, apv, rv, partials);
     return hipGetLastError();
 }
 
@@ -893,11 +901,11 @@ hipError_t launch_scatter_coo(double *A, long lda, int row0, const int *I, const
 }
 
 hipError_t launch_mailbox_allgather(const MailboxView &mv, int chan, unsigned long long epoch, const double *src,
-                                    int count, double *dst, long dst_stride, int copy_self, int reduce_first,
-                                    long long timeout_ticks, int *err, hipStream_t s)
+                                    int count, int tail_off, int tail_n, double *dst, long dst_stride, int sum_off,
+                                    int copy_self, long long timeout_ticks, int *err, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_mailbox_allgather, dim3(mv.nranks), dim3(256), 0, s, mv, chan, epoch, src, count, dst,
-                       dst_stride, copy_self, reduce_first, timeout_ticks, err);
+    hipLaunchKernelGGL(k_mailbox_allgather, dim3(mv.nranks), dim3(256), 0, s, mv, chan, epoch, src, count, tail_off, tail_n,
+                       dst, dst_stride, sum_off, copy_self, timeout_ticks, err);
     return hipGetLastError();
 }
 

@@ -7,10 +7,10 @@
 //     enqueues kernels and polls one int every `check_every` iterations, so the stream never drains;
 //   * after convergence every kernel of the remaining enqueued iterations exits at its first
 //     instruction, which reproduces the reference's `break` (cg.cc:120-121) exactly;
-//   * one iteration = two kernels (K1 fused GEMV, K3 x/r update) and two exchanges:
-//     MPI_Allreduce(p.Ap) -> all-gather of kSlots doubles per rank + rank-ordered sum inside K3;
-//     MPI_Allreduce(r.r) + MPI_Allgatherv(p) -> ONE in-place all-gather of equal segments
-//     [r slice | r.r partial]; every rank then forms p = r + beta p itself inside K1 (cgx_kernels.hip).
+//   * one iteration = two kernels (K1 fused GEMV, K3 x/r update) and ONE exchange: an in-place all-gather of
+//     equal segments [Ap slice | p.Ap partials] replaces MPI_Allreduce(p.Ap), MPI_Allreduce(r.r) and
+//     MPI_Allgatherv(p): r and p are replicated, every rank updates all of r from the gathered Ap, reduces r.r
+//     over all n rows in one fixed order (bit-identical everywhere) and forms p = r + beta p inside the next K1.
 #include "../../include/cgx.h"
 
 #include <hip/hip_runtime.h>
@@ -49,19 +49,19 @@ struct Shard {
     int row0 = 0;
     int rows = 0;
     double *A = nullptr;         // rows x lda, row-major, pad columns zero
-    double *b = nullptr;         // rows
+    double *b_full = nullptr;    // n doubles: b is replicated like r (the reference builds the full b on every rank, cg.cc:218-234)
     double *x = nullptr;         // rows
-    double *Ap = nullptr;        // rows
     double *p[2] = {nullptr, nullptr};   // lda doubles each: the replicated p (cg.cc:57), ping-pong over iterations
-    double *rg = nullptr;        // nranks * S doubles: exchanged segments [r slice | scalars] (cgx::SegView)
+    double *apg = nullptr;       // nranks * S doubles: exchanged segments [Ap slice | p.Ap partials] (cgx::SegView apv)
+    double *rbuf = nullptr;      // lda + kSlots doubles: the replicated r and its scalars (cgx::SegView rv, one segment)
     double *partials = nullptr;  // scratch: per-workgroup partial sums of K3 and of the setup kernels
-    double *k1_part = nullptr;   // npart doubles: K1's per-workgroup p.Ap partials (send buffer of exchange 1)
-    double *k1_gath = nullptr;   // nranks * npart doubles: every rank's K1 partials (SELF: == k1_part)
     Scalars *sc = nullptr;
     double *gathered = nullptr;  // kMaxRanks * kSlots doubles (DEBUG scalars of all ranks)
     cgx::GemvPlan plan{};
-    cgx::SegView seg{};
+    cgx::SegView apv{}, rv{};
     int npartials = 0;
+    double *Ap() const { return apg + (size_t)rank * apv.S; }          // this shard's Ap slice (K1 output)
+    double *k1_part() const { return Ap() + apv.Sr; }                   // this shard's p.Ap partials (segment tail)
 };
 
 }  // namespace
@@ -168,15 +168,13 @@ void partition_rows(int N, int psize, int *start_rows, int *num_rows)
 void free_shard(Shard &s)
 {
     (void)hipFree(s.A);
-    (void)hipFree(s.b);
+    (void)hipFree(s.b_full);
     (void)hipFree(s.x);
-    (void)hipFree(s.Ap);
     (void)hipFree(s.p[0]);
     (void)hipFree(s.p[1]);
-    (void)hipFree(s.rg);
+    (void)hipFree(s.apg);
+    (void)hipFree(s.rbuf);
     (void)hipFree(s.partials);
-    (void)hipFree(s.k1_part);
-    if (s.k1_gath != s.k1_part) (void)hipFree(s.k1_gath);
     (void)hipFree(s.sc);
     (void)hipFree(s.gathered);
     s = Shard{};
@@ -221,6 +219,7 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
             HIP_TRY(ctx, hipMemsetAsync(s.p[0], 0, (size_t)ctx->lda * sizeof(double), ctx->stream));
             HIP_TRY(ctx, hipMemsetAsync(s.p[1], 0, (size_t)ctx->lda * sizeof(double), ctx->stream));
             HIP_TRY(ctx, hipMemsetAsync(s.sc, 0, sizeof(Scalars), ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(s.apg, 0, (size_t)ctx->nranks * ctx->seg_S * sizeof(double), ctx->stream));
         }
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         return CGX_OK;
@@ -234,9 +233,7 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
     partition_rows(n, ctx->nranks, ctx->start_rows.data(), ctx->num_rows.data());
     int max_rows = 0;
     for (int q = 0; q < ctx->nranks; ++q) max_rows = std::max(max_rows, ctx->num_rows[q]);
-    ctx->seg_Sr = std::max((max_rows + 1) / 2 * 2, 2);   // r part, padded to an even count
-    if (ctx->nranks == 1) ctx->seg_Sr = (int)ctx->lda;   // one shard: r is contiguous and zero padded like p (16-B loads)
-    ctx->seg_S = ctx->seg_Sr + cgx::kSlots;
+    ctx->seg_Sr = std::max((max_rows + 1) / 2 * 2, 2);   // Ap slice, padded to an even count
 
     int variant = ctx->cfg.gemv_variant;
     if (variant <= 0) {
@@ -249,8 +246,7 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
     if (ctx->cfg.comm_mode == CGX_COMM_P2P) {
         // mailbox layout of this problem: flags, then per channel [2 parities][nranks] slots
         const long flags_bytes = (long)cgx::kP2pChannels * cgx::kMaxRanks * cgx::kP2pFlagStride;
-        const long slot[cgx::kP2pChannels] = {((long)ctx->npart * 8 + 15) / 16 * 16, ((long)ctx->seg_S * 8 + 15) / 16 * 16,
-                                              (long)cgx::kSlots * 8};
+        const long slot[cgx::kP2pChannels] = {16, ((long)(ctx->seg_Sr + 1) * 8 + 15) / 16 * 16, (long)cgx::kSlots * 8};
         long off = flags_bytes;
         for (int c = 0; c < cgx::kP2pChannels; ++c) {
             ctx->mv.data_off[c] = off;
@@ -261,6 +257,8 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
             return fail(ctx, CGX_ERR_P2P, "mailbox too small for this problem: need " + std::to_string(off) +
                                               " bytes (raise cgx_config.p2p_mailbox_kib)");
     }
+    const int seg_tail = (ctx->npart + 1 + 1) / 2 * 2;   // npart partials + 1 slot for a rank's folded sum, even
+    ctx->seg_S = ctx->seg_Sr + seg_tail;
     const int nlocal = (ctx->cfg.comm_mode == CGX_COMM_LOOPBACK) ? ctx->nranks : 1;
     ctx->shards.resize(nlocal);
     for (int i = 0; i < nlocal; ++i) {
@@ -270,31 +268,27 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
         s.rows = ctx->num_rows[s.rank];
         s.plan = cgx::plan_gemv(variant, s.rows, (int)ctx->lda);
         const size_t rows_alloc = (size_t)std::max(s.rows, 1);
-        s.npartials = std::max(s.plan.grid, 3 * cgx::update_xr_grid(s.rows)) + 8;
+        s.npartials = 3 * cgx::update_xr_grid(n) + 8;
         HIP_TRY(ctx, hipMalloc(&s.A, rows_alloc * (size_t)ctx->lda * sizeof(double)));
-        HIP_TRY(ctx, hipMalloc(&s.b, rows_alloc * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&s.b_full, (size_t)n * sizeof(double)));
         HIP_TRY(ctx, hipMalloc(&s.x, rows_alloc * sizeof(double)));
-        HIP_TRY(ctx, hipMalloc(&s.Ap, rows_alloc * sizeof(double)));
         HIP_TRY(ctx, hipMalloc(&s.p[0], (size_t)ctx->lda * sizeof(double)));
         HIP_TRY(ctx, hipMalloc(&s.p[1], (size_t)ctx->lda * sizeof(double)));
-        const size_t rg_bytes = (size_t)ctx->nranks * ctx->seg_S * sizeof(double);
-        HIP_TRY(ctx, hipMalloc(&s.rg, rg_bytes));
-        s.seg = cgx::SegView{s.rg, ctx->seg_S, ctx->seg_Sr, n / ctx->nranks, ctx->nranks, n, s.rank, 0, 0, 0};
-        cgx::seg_finalize(&s.seg);
+        const size_t apg_bytes = (size_t)ctx->nranks * ctx->seg_S * sizeof(double);
+        const size_t rbuf_bytes = (size_t)(ctx->lda + cgx::kSlots) * sizeof(double);
+        HIP_TRY(ctx, hipMalloc(&s.apg, apg_bytes));
+        HIP_TRY(ctx, hipMalloc(&s.rbuf, rbuf_bytes));
+        s.apv = cgx::SegView{s.apg, ctx->seg_S, ctx->seg_Sr, n / ctx->nranks, ctx->nranks, n, s.rank, 0, 0, 0};
+        cgx::seg_finalize(&s.apv);
+        s.rv = cgx::SegView{s.rbuf, (int)ctx->lda + cgx::kSlots, (int)ctx->lda, n, 1, n, 0, 0, 0, 0};
+        cgx::seg_finalize(&s.rv);
         HIP_TRY(ctx, hipMalloc(&s.partials, (size_t)s.npartials * sizeof(double)));
-        HIP_TRY(ctx, hipMalloc(&s.k1_part, (size_t)ctx->npart * sizeof(double)));
-        HIP_TRY(ctx, hipMemsetAsync(s.k1_part, 0, (size_t)ctx->npart * sizeof(double), ctx->stream));
-        if (ctx->cfg.comm_mode == CGX_COMM_SELF) {
-            s.k1_gath = s.k1_part;
-        } else {
-            HIP_TRY(ctx, hipMalloc(&s.k1_gath, (size_t)ctx->nranks * ctx->npart * sizeof(double)));
-            HIP_TRY(ctx, hipMemsetAsync(s.k1_gath, 0, (size_t)ctx->nranks * ctx->npart * sizeof(double), ctx->stream));
-        }
         HIP_TRY(ctx, hipMalloc(&s.sc, sizeof(Scalars)));
         HIP_TRY(ctx, hipMalloc(&s.gathered, (size_t)cgx::kMaxRanks * cgx::kSlots * sizeof(double)));
         HIP_TRY(ctx, hipMemsetAsync(s.p[0], 0, (size_t)ctx->lda * sizeof(double), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(s.p[1], 0, (size_t)ctx->lda * sizeof(double), ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(s.rg, 0, rg_bytes, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(s.apg, 0, apg_bytes, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(s.rbuf, 0, rbuf_bytes, ctx->stream));
         if (s.rows <= 0) HIP_TRY(ctx, hipMemsetAsync(s.A, 0, (size_t)ctx->lda * sizeof(double), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(s.partials, 0, (size_t)s.npartials * sizeof(double), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(s.sc, 0, sizeof(Scalars), ctx->stream));
@@ -320,17 +314,16 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
 
 // CGX_COMM_P2P: one lean all-gather kernel over the IPC-mapped mailboxes (cgx_kernels.hip).
 cgx_status p2p_allgather(cgx_ctx *ctx, int chan, const double *src, int count, double *dst, long dst_stride,
-                         int copy_self, int reduce_first = 0)
+                         int copy_self, int tail_off = 0, int tail_n = 0, int sum_off = 0)
 {
     if (!ctx->p2p_ready) return fail(ctx, CGX_ERR_P2P, "cgx_p2p_import has not been called");
-    if ((long)(reduce_first ? 1 : count) * 8 > ctx->mv.slot_bytes[chan])
+    if ((long)(count + (tail_n > 0 ? 1 : 0)) * 8 > ctx->mv.slot_bytes[chan])
         return fail(ctx, CGX_ERR_P2P, "p2p payload larger than its slot");
     const unsigned long long epoch = ++ctx->p2p_epoch[chan];
-    HIP_TRY(ctx, cgx::launch_mailbox_allgather(ctx->mv, chan, epoch, src, count, dst, dst_stride, copy_self, reduce_first,
-                                               ctx->p2p_timeout_ticks, ctx->d_p2p_err, ctx->stream));
+    HIP_TRY(ctx, cgx::launch_mailbox_allgather(ctx->mv, chan, epoch, src, count, tail_off, tail_n, dst, dst_stride, sum_off,
+                                               copy_self, ctx->p2p_timeout_ticks, ctx->d_p2p_err, ctx->stream));
     return CGX_OK;
 }
-
 
 // Scalars: every shard contributes sc->local[kSlots]; afterwards every shard's gathered[] holds all of them.
 // Replaces MPI_Allreduce (cg.cc:92,106,117).  In SELF mode the consumers read sc->local directly.
@@ -354,37 +347,11 @@ cgx_status gather_scalars(cgx_ctx *ctx)
     }
 }
 
-// Exchange 1: every rank's K1 partials (npart doubles, zero beyond its own grid) to every rank.  Replaces the
-// MPI_Allreduce of p.Ap (cg.cc:106): K3 folds all nranks*npart values in one fixed order on every rank.
-cgx_status gather_k1_partials(cgx_ctx *ctx)
-{
-    const size_t np = (size_t)ctx->npart;
-    switch (ctx->cfg.comm_mode) {
-    case CGX_COMM_SELF:
-        return CGX_OK;
-    case CGX_COMM_LOOPBACK:
-        for (auto &dst : ctx->shards)
-            for (auto &src : ctx->shards)
-                HIP_TRY(ctx, hipMemcpyAsync(dst.k1_gath + src.rank * np, src.k1_part, np * sizeof(double),
-                                            hipMemcpyDeviceToDevice, ctx->stream));
-        return CGX_OK;
-    case CGX_COMM_P2P: {
-        Shard &s = ctx->shards[0];
-        // one double per rank travels: the exchange kernel folds this rank's partials first
-        return p2p_allgather(ctx, 0, s.k1_part, ctx->npart, s.k1_gath, 1, 1, 1);
-    }
-    default: {
-        Shard &s = ctx->shards[0];
-        NCCL_TRY(ctx, ctx->rccl->AllGather(s.k1_part, s.k1_gath, np, ncclDouble, ctx->comm, ctx->stream));
-        return CGX_OK;
-    }
-    }
-}
-
-// Exchange segments: every shard's own segment [r slice | scalars] inside its rg is current; afterwards all
-// P segments are.  Replaces MPI_Allgatherv (cg.cc:87-88,135-136) AND the MPI_Allreduce of r.r (cg.cc:92,117)
-// in one message; segments have the same size on every rank, so N % P != 0 needs no special case.
-cgx_status gather_segments(cgx_ctx *ctx)
+// THE exchange of an iteration: every shard's own segment [Ap slice | p.Ap partials] inside its apg is current;
+// afterwards all P segments are.  Replaces MPI_Allreduce (cg.cc:106) and MPI_Allgatherv (cg.cc:135-136); segments
+// have the same size on every rank, so N % P != 0 needs no special case.  with_tail = false moves the slices only
+// (used for the final gather of x, MPI_Gatherv cg.cc:140-142).
+cgx_status gather_segments(cgx_ctx *ctx, bool with_tail)
 {
     const size_t S = (size_t)ctx->seg_S;
     switch (ctx->cfg.comm_mode) {
@@ -394,16 +361,18 @@ cgx_status gather_segments(cgx_ctx *ctx)
         for (auto &dst : ctx->shards)
             for (auto &src : ctx->shards)
                 if (dst.rank != src.rank)
-                    HIP_TRY(ctx, hipMemcpyAsync(dst.rg + src.rank * S, src.rg + src.rank * S, S * sizeof(double),
+                    HIP_TRY(ctx, hipMemcpyAsync(dst.apg + src.rank * S, src.apg + src.rank * S, S * sizeof(double),
                                                 hipMemcpyDeviceToDevice, ctx->stream));
         return CGX_OK;
     case CGX_COMM_P2P: {
+        // the exchange kernel folds this rank's partials and ships [Ap slice | one double]
         Shard &s = ctx->shards[0];
-        return p2p_allgather(ctx, 1, s.rg + s.rank * S, ctx->seg_S, s.rg, ctx->seg_S, 0);
+        return p2p_allgather(ctx, 1, s.Ap(), ctx->seg_Sr, s.apg, ctx->seg_S, 0, ctx->seg_Sr, with_tail ? ctx->npart : 0,
+                             ctx->seg_Sr + ctx->npart);
     }
     default: {
         Shard &s = ctx->shards[0];
-        NCCL_TRY(ctx, ctx->rccl->AllGather(s.rg + s.rank * S, s.rg, S, ncclDouble, ctx->comm, ctx->stream));
+        NCCL_TRY(ctx, ctx->rccl->AllGather(s.Ap(), s.apg, S, ncclDouble, ctx->comm, ctx->stream));
         return CGX_OK;
     }
     }
@@ -424,7 +393,7 @@ cgx_status take_event(cgx_ctx *ctx, hipEvent_t *out)
 // K1, plain form (vector given): initial residual, DEBUG verification, probes.
 cgx_status run_gemv_plain(cgx_ctx *ctx, Shard &s, const double *v_full)
 {
-    HIP_TRY(ctx, cgx::launch_gemv_plain(s.plan, s.A, ctx->lda, s.rows, v_full, v_full + s.row0, s.Ap, s.k1_part, s.sc,
+    HIP_TRY(ctx, cgx::launch_gemv_plain(s.plan, s.A, ctx->lda, s.rows, v_full, v_full + s.row0, s.Ap(), s.k1_part(), s.sc,
                                         ctx->stream));
     return CGX_OK;
 }
@@ -440,8 +409,8 @@ cgx_status run_gemv_fused(cgx_ctx *ctx, Shard &s, int k)
         CGX_TRY(take_event(ctx, &e1));
         HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
     }
-    HIP_TRY(ctx, cgx::launch_gemv_fused(s.plan, s.A, ctx->lda, s.rows, s.row0, s.p[k & 1], s.p[(k + 1) & 1], s.seg, s.Ap,
-                                        s.k1_part, s.sc, k, ctx->tol, ctx->stream));
+    HIP_TRY(ctx, cgx::launch_gemv_fused(s.plan, s.A, ctx->lda, s.rows, s.row0, s.p[k & 1], s.p[(k + 1) & 1], s.rv, s.Ap(),
+                                        s.k1_part(), s.sc, k, ctx->tol, ctx->stream));
     if (timed) HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
     return CGX_OK;
 }
@@ -460,18 +429,17 @@ cgx_status harvest_gemv_events(cgx_ctx *ctx)
     return CGX_OK;
 }
 
-// ---- one body of the loop cg.cc:96-137: two kernels, two exchanges ------------------------------------
+// ---- one body of the loop cg.cc:96-137: two kernels, one exchange ------------------------------------
 cgx_status enqueue_iteration(cgx_ctx *ctx, int k)
 {
     hipStream_t st = ctx->stream;
-    // tail of iteration k-1 (cg.cc:117-132) + GEMV and p.Ap of iteration k (cg.cc:100-105)
+    // tail of iteration k-1 (cg.cc:117-132) + GEMV and p.Ap partials of iteration k (cg.cc:100-105)
     for (auto &s : ctx->shards) CGX_TRY(run_gemv_fused(ctx, s, k));
-    CGX_TRY(gather_k1_partials(ctx));                                                                // cg.cc:106
+    CGX_TRY(gather_segments(ctx, true));                                                             // cg.cc:106
+    const bool folded = ctx->cfg.comm_mode == CGX_COMM_P2P;   // the exchange kernel already folded each rank's partials
     for (auto &s : ctx->shards)
-        HIP_TRY(ctx, cgx::launch_update_xr(s.rows, s.p[(k + 1) & 1] + s.row0, s.Ap, s.x, s.seg, s.sc, k & 1, s.k1_gath,
-                                           ctx->cfg.comm_mode == CGX_COMM_P2P ? ctx->nranks : ctx->nranks * ctx->npart,
-                                           s.partials, st));                                         // cg.cc:105-116
-    CGX_TRY(gather_segments(ctx));                                                                   // cg.cc:117,135-136
+        HIP_TRY(ctx, cgx::launch_update_xr(ctx->n, s.rows, s.row0, s.p[(k + 1) & 1], s.apv, folded ? ctx->npart : 0,
+                                           folded ? 1 : ctx->npart, s.x, s.rv, s.sc, k & 1, s.partials, st));   // cg.cc:105-116
     return CGX_OK;
 }
 
@@ -902,9 +870,8 @@ cgx_status cgx_set_source_term(cgx_ctx *ctx, const double *b)
     if (ctx->n <= 0 || ctx->shards.empty()) return fail(ctx, CGX_ERR_BAD_ARG, "set the matrix before the source term");
     ctx->b_host.assign(b, b + ctx->n);
     for (auto &s : ctx->shards)
-        if (s.rows > 0)
-            HIP_TRY(ctx, hipMemcpyAsync(s.b, ctx->b_host.data() + s.row0, (size_t)s.rows * sizeof(double),
-                                        hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(s.b_full, ctx->b_host.data(), (size_t)ctx->n * sizeof(double), hipMemcpyHostToDevice,
+                                    ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_b = true;
     return CGX_OK;
@@ -941,24 +908,25 @@ cgx_status cgx_solve_begin(cgx_ctx *ctx, const double *x0)
     const size_t vec_bytes = (size_t)ctx->lda * sizeof(double);
     for (auto &s : ctx->shards) {
         HIP_TRY(ctx, hipMemsetAsync(s.sc, 0, sizeof(Scalars), st));
-        HIP_TRY(ctx, hipMemsetAsync(s.rg, 0, (size_t)ctx->nranks * ctx->seg_S * sizeof(double), st));
+        HIP_TRY(ctx, hipMemsetAsync(s.apg, 0, (size_t)ctx->nranks * ctx->seg_S * sizeof(double), st));
+        HIP_TRY(ctx, hipMemsetAsync(s.rbuf, 0, (size_t)(ctx->lda + cgx::kSlots) * sizeof(double), st));
         // x (initial guess) replicated for the first GEMV, x_sub = x[rows]  (cg.cc:72, 80)
         HIP_TRY(ctx, hipMemcpyAsync(s.p[0], x0, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
         if (s.rows > 0)
             HIP_TRY(ctx, hipMemcpyAsync(s.x, s.p[0] + s.row0, (size_t)s.rows * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
     for (auto &s : ctx->shards) CGX_TRY(run_gemv_plain(ctx, s, s.p[0]));                             // cg.cc:79-81
+    CGX_TRY(gather_segments(ctx, false));
     for (auto &s : ctx->shards)
-        HIP_TRY(ctx, cgx::launch_init_residual(s.rows, s.b, s.Ap, s.seg, s.partials, st));           // cg.cc:82
+        HIP_TRY(ctx, cgx::launch_init_residual(n, s.b_full, s.apv, s.rv, s.partials, st));           // cg.cc:82
     for (auto &s : ctx->shards)
-        HIP_TRY(ctx, cgx::launch_reduce_partials(s.partials, cgx::update_xr_grid(s.rows),
-                                                 s.rg + (size_t)s.rank * ctx->seg_S + ctx->seg_Sr + cgx::kSlotRr, st));   // cg.cc:91
+        HIP_TRY(ctx, cgx::launch_reduce_partials(s.partials, cgx::update_xr_grid(n),
+                                                 s.rbuf + ctx->lda + cgx::kSlotRr, st));             // cg.cc:91-92
     for (auto &s : ctx->shards) {
         // p_old of iteration 0 is 0, so K1(0) forms p = r + 0*0 = r  (p_sub = r_sub, cg.cc:85)
         HIP_TRY(ctx, hipMemsetAsync(s.p[0], 0, vec_bytes, st));
         HIP_TRY(ctx, hipMemsetAsync(s.p[1], 0, vec_bytes, st));
     }
-    CGX_TRY(gather_segments(ctx));                                                                   // cg.cc:87-88,92
     ctx->in_solve = true;
     return CGX_OK;
 }
@@ -1008,7 +976,7 @@ cgx_status cgx_solve_end(cgx_ctx *ctx, double *x, cgx_result *res)
     hipStream_t st = ctx->stream;
     // The convergence test of the last enqueued iteration is normally done by the NEXT K1; when the loop
     // ran out there is none, so close it here (cg.cc:117-121,132).
-    for (auto &s : ctx->shards) HIP_TRY(ctx, cgx::launch_close_iteration(s.sc, s.seg, ctx->k, ctx->tol, st));
+    for (auto &s : ctx->shards) HIP_TRY(ctx, cgx::launch_close_iteration(s.sc, s.rv, ctx->k, ctx->tol, st));
     CGX_TRY(read_flags_sync(ctx));
     const int k_exit = ctx->done ? ctx->k_final : ctx->k;
 
@@ -1016,12 +984,12 @@ cgx_status cgx_solve_end(cgx_ctx *ctx, double *x, cgx_result *res)
     // (cg.cc:144-151) with the same K1, distributed over the shards instead of rank 0 alone.
     for (auto &s : ctx->shards)
         if (s.rows > 0)
-            HIP_TRY(ctx, hipMemcpyAsync(s.rg + (size_t)s.rank * ctx->seg_S, s.x, (size_t)s.rows * sizeof(double),
-                                        hipMemcpyDeviceToDevice, st));
-    CGX_TRY(gather_segments(ctx));
-    for (auto &s : ctx->shards) HIP_TRY(ctx, cgx::launch_unpack_segments(s.seg, s.p[0], ctx->lda, st));
+            HIP_TRY(ctx, hipMemcpyAsync(s.Ap(), s.x, (size_t)s.rows * sizeof(double), hipMemcpyDeviceToDevice, st));
+    CGX_TRY(gather_segments(ctx, false));
+    for (auto &s : ctx->shards) HIP_TRY(ctx, cgx::launch_unpack_segments(s.apv, s.p[0], ctx->lda, st));
     for (auto &s : ctx->shards) CGX_TRY(run_gemv_plain(ctx, s, s.p[0]));
-    for (auto &s : ctx->shards) HIP_TRY(ctx, cgx::launch_debug_norms(s.rows, s.Ap, s.b, s.x, s.partials, st));
+    for (auto &s : ctx->shards)
+        HIP_TRY(ctx, cgx::launch_debug_norms(s.rows, s.Ap(), s.b_full + s.row0, s.x, s.partials, st));
     for (auto &s : ctx->shards)
         HIP_TRY(ctx, cgx::launch_reduce_partials3(s.partials, cgx::update_xr_grid(s.rows), s.sc->local, st));
     CGX_TRY(gather_scalars(ctx));
@@ -1081,10 +1049,10 @@ cgx_status cgx_probe_gemv(cgx_ctx *ctx, const double *p, double *y, double *pAp)
         HIP_TRY(ctx, hipMemsetAsync(s.sc, 0, sizeof(Scalars), st));
         HIP_TRY(ctx, hipMemcpyAsync(s.p[0], p, (size_t)ctx->n * sizeof(double), hipMemcpyHostToDevice, st));
         CGX_TRY(run_gemv_plain(ctx, s, s.p[0]));
-        HIP_TRY(ctx, cgx::launch_reduce_partials(s.k1_part, s.plan.grid, &s.sc->local[cgx::kSlotConj], st));
+        HIP_TRY(ctx, cgx::launch_reduce_partials(s.k1_part(), s.plan.grid, &s.sc->local[cgx::kSlotConj], st));
         double part = 0.0;
         if (s.rows > 0)
-            HIP_TRY(ctx, hipMemcpyAsync(y + s.row0, s.Ap, (size_t)s.rows * sizeof(double), hipMemcpyDeviceToHost, st));
+            HIP_TRY(ctx, hipMemcpyAsync(y + s.row0, s.Ap(), (size_t)s.rows * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipMemcpyAsync(&part, &s.sc->local[cgx::kSlotConj], sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(ctx, hipStreamSynchronize(st));
         total += part;
@@ -1126,52 +1094,55 @@ cgx_status cgx_probe_vector_ops(cgx_ctx *ctx, int n, double alpha, double beta, 
     // A single-shard problem of length n around the PRODUCTION kernels: K3 for x/r/r.r, then the fused K1 of
     // the next iteration (on a 1 x n zero matrix) for p = r + beta p.
     const long lda = ((long)n + 15) / 16 * 16;
-    const int Sr = (int)lda, S = Sr + cgx::kSlots;   // single shard: r zero padded up to lda
+    const int Sr = std::max((n + 1) / 2 * 2, 2), S = Sr + 2;      // Ap segment: [Ap (Sr) | one partial, pad]
     const size_t bytes = (size_t)n * sizeof(double), vbytes = (size_t)lda * sizeof(double);
     const int grid = cgx::update_xr_grid(n);
-    double *dx = nullptr, *dAp = nullptr, *dp0 = nullptr, *dp1 = nullptr, *dseg = nullptr, *dpart = nullptr, *dA = nullptr,
+    double *dx = nullptr, *dp0 = nullptr, *dp1 = nullptr, *dap = nullptr, *drb = nullptr, *dpart = nullptr, *dA = nullptr,
            *dAp1 = nullptr;
     Scalars *dsc = nullptr;
     HIP_TRY(ctx, hipMalloc(&dx, bytes));
-    HIP_TRY(ctx, hipMalloc(&dAp, bytes));
     HIP_TRY(ctx, hipMalloc(&dp0, vbytes));
     HIP_TRY(ctx, hipMalloc(&dp1, vbytes));
-    HIP_TRY(ctx, hipMalloc(&dseg, (size_t)S * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc(&dap, (size_t)S * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc(&drb, (size_t)(lda + cgx::kSlots) * sizeof(double)));
     HIP_TRY(ctx, hipMalloc(&dpart, (size_t)(grid + 8) * sizeof(double)));
     HIP_TRY(ctx, hipMalloc(&dA, vbytes));
-    HIP_TRY(ctx, hipMalloc(&dAp1, 8 * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc(&dAp1, 64 * sizeof(double)));
     HIP_TRY(ctx, hipMalloc(&dsc, sizeof(Scalars)));
-    cgx::SegView sv{dseg, S, Sr, n, 1, n, 0, 0, 0, 0};
-    cgx::seg_finalize(&sv);
-    // Force the wanted alpha: with rsold = alpha and conj = 1, K3 computes alpha / max(1, alpha*1e-14) = alpha.
+    cgx::SegView apv{dap, S, Sr, n, 1, n, 0, 0, 0, 0};
+    cgx::seg_finalize(&apv);
+    cgx::SegView rv{drb, (int)lda + cgx::kSlots, (int)lda, n, 1, n, 0, 0, 0, 0};
+    cgx::seg_finalize(&rv);
+    // Force the wanted alpha: with rsold = alpha and p.Ap = 1, K3 computes alpha / max(1, alpha*1e-14) = alpha.
     Scalars hs{};
     hs.rs[0] = alpha;
-    hs.local[cgx::kSlotConj] = 1.0;
+    const double one = 1.0;
     HIP_TRY(ctx, hipMemsetAsync(dp0, 0, vbytes, st));
     HIP_TRY(ctx, hipMemsetAsync(dp1, 0, vbytes, st));
-    HIP_TRY(ctx, hipMemsetAsync(dseg, 0, (size_t)S * sizeof(double), st));
+    HIP_TRY(ctx, hipMemsetAsync(dap, 0, (size_t)S * sizeof(double), st));
+    HIP_TRY(ctx, hipMemsetAsync(drb, 0, (size_t)(lda + cgx::kSlots) * sizeof(double), st));
     HIP_TRY(ctx, hipMemsetAsync(dA, 0, vbytes, st));
     HIP_TRY(ctx, hipMemcpyAsync(dsc, &hs, sizeof hs, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(dx, x, bytes, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(dseg, r, bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(drb, r, bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(dp0, p, bytes, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(dAp, Ap, bytes, hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, cgx::launch_update_xr(n, dp0, dAp, dx, sv, dsc, 0, &dsc->local[cgx::kSlotConj], 1, dpart, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dap, Ap, bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dap + Sr, &one, sizeof(double), hipMemcpyHostToDevice, st));   // the one p.Ap "partial"
+    HIP_TRY(ctx, cgx::launch_update_xr(n, n, 0, dp0, apv, 0, 1, dx, rv, dsc, 0, dpart, st));
     double rr_host = 0.0;
-    HIP_TRY(ctx, hipMemcpyAsync(&rr_host, dseg + Sr + cgx::kSlotRr, sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(&rr_host, drb + lda + cgx::kSlotRr, sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(x, dx, bytes, hipMemcpyDeviceToHost, st));
-    HIP_TRY(ctx, hipMemcpyAsync(r, dseg, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(r, drb, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    // Force the wanted beta: rsold = 1, gathered r.r = beta  =>  K1(k=1) computes beta/1.
-    const double one = 1.0;
+    // Force the wanted beta: rsold = 1, r.r = beta  =>  K1(k=1) computes beta/1.
     HIP_TRY(ctx, hipMemcpyAsync(&dsc->rs[0], &one, sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(dseg + Sr + cgx::kSlotRr, &beta, sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(drb + lda + cgx::kSlotRr, &beta, sizeof(double), hipMemcpyHostToDevice, st));
     cgx::GemvPlan plan = cgx::plan_gemv(ctx->cfg.gemv_variant, 1, (int)lda);
-    HIP_TRY(ctx, cgx::launch_gemv_fused(plan, dA, lda, 1, 0, dp0, dp1, sv, dAp1, dpart, dsc, 1, -1.0 /* never converges */, st));
+    HIP_TRY(ctx, cgx::launch_gemv_fused(plan, dA, lda, 1, 0, dp0, dp1, rv, dAp1, dAp1 + 8, dsc, 1, -1.0 /* never converges */, st));
     HIP_TRY(ctx, hipMemcpyAsync(p, dp1, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (rr) *rr = rr_host;
-    (void)hipFree(dx); (void)hipFree(dAp); (void)hipFree(dp0); (void)hipFree(dp1); (void)hipFree(dseg);
+    (void)hipFree(dx); (void)hipFree(dp0); (void)hipFree(dp1); (void)hipFree(dap); (void)hipFree(drb);
     (void)hipFree(dpart); (void)hipFree(dA); (void)hipFree(dAp1); (void)hipFree(dsc);
     return CGX_OK;
 }
