@@ -22,13 +22,13 @@ struct Scalars {
     double dbg[4];
     int    done;           // set when sqrt(rsnew) < tol (cg.cc:120-121); later kernels exit at once
     int    k_final;        // k of the converging iteration
-    unsigned counter[2];   // arrival tickets of the in-kernel reductions of K1 / K3 (always 0 between launches)
+    unsigned pad[2];
 };
 
 // Segmented vector: P equal segments of S doubles, segment q = [ slice of rank q (Sr doubles, zero padded) |
 // tail ].  Used for the exchanged Ap ([Ap slice | p.Ap partials], one in-place all-gather per iteration in
 // place of MPI_Allreduce cg.cc:106 + MPI_Allgatherv cg.cc:135-136) and, with nranks = 1, for the replicated
-// r ([r (lda) | scalars]).
+// r ([r (lda) | r.r partials of K3's workgroups]).
 struct SegView {
     double *base;     // this shard's copy of all P segments
     int S, Sr;        // segment stride, r part
@@ -70,7 +70,7 @@ hipError_t launch_gemv_fused(const GemvPlan &plan, const double *A, long lda, in
 
 // K3: p.Ap = fixed-order sum over all ranks q of the tail_count doubles at tail_off of segment q's tail;
 // alpha = rsold / max(p.Ap, rsold*1e-14); x_sub += alpha p_sub (own rows); r -= alpha Ap for ALL n rows (r is
-// replicated, rv = [r (lda) | scalars]); scalar slot kSlotRr of rv = sum r_i^2 (last-arriving workgroup).  cg.cc:105-116.
+// replicated, rv = [r (lda) | one r.r partial per K3 workgroup]); the next K1's head folds the partials.  cg.cc:105-116.
 hipError_t launch_update_xr(int n, int rows, int row0, const double *p_new, SegView apv, int tail_off, int tail_count,
                             double *x, SegView rv, Scalars *sc, int parity, double *partials, hipStream_t s);
 int update_xr_grid(int count);
@@ -83,7 +83,7 @@ hipError_t launch_close_iteration(Scalars *sc, SegView seg, int k, double tol, h
 hipError_t launch_reduce_partials(const double *partials, int n, double *out, hipStream_t s);
 hipError_t launch_reduce_partials3(const double *partials, int n, double *out3, hipStream_t s);
 
-// Initial residual (cg.cc:79-85): r = b - Ap for all n rows (Ap from the gathered segments); partials[wg] = sum r_i^2.
+// Initial residual (cg.cc:79-85): r = b - Ap for all n rows (Ap from the gathered segments); rv tail[wg] = sum r_i^2.
 hipError_t launch_init_residual(int n, const double *b_full, SegView apv, SegView rv, double *partials, hipStream_t s);
 
 // v_full[c] = segment value of column c (c < n), 0 for the pad: turns gathered slices into a replicated vector.

@@ -61,42 +61,6 @@ __device__ __forceinline__ double block_sum(double v, double *lds /* >= WAVES do
     return s;
 }
 
-// Grid-wide sum of one double per workgroup without a second launch: every workgroup publishes its
-// partial write-through (sc1 store), drains, and takes a ticket; the workgroup that draws the last
-// ticket folds all partials in index order (so the result does not depend on arrival order) and resets
-// the ticket word.  This is the counter form of the agent-scope hand-off (cdna_hip_programming.md
-// Guideline 16 / MI355X_MICROARCH.md "Valid forms", first table row): sc1 payload stores, every storing
-// lane's s_waitcnt vmcnt(0) before its own atomic add, last arriver told by the add's return value,
-// sc1 loads of the payload; the agent-scope acquire is kept as well.
-template <int WAVES>
-__device__ __forceinline__ void grid_sum_last_arriver(double d /* thread 0 */, double *partials, unsigned *counter,
-                                                      double *out, double *lds, int *s_flag)
-{
-    const unsigned nwg = gridDim.x;
-    if (threadIdx.x == 0) {
-        __hip_atomic_store(reinterpret_cast<unsigned long long *>(partials) + blockIdx.x,
-                           (unsigned long long)__double_as_longlong(d), CGX_RLX_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const unsigned t = __hip_atomic_fetch_add(counter, 1u, CGX_RLX_AGENT);
-        *s_flag = (t == nwg - 1) ? 1 : 0;
-    }
-    __syncthreads();
-    if (*s_flag) {   // workgroup-uniform
-        if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        double s = 0.0;
-        for (unsigned i = threadIdx.x; i < nwg; i += WAVES * 64)
-            s += __longlong_as_double((long long)__hip_atomic_load(
-                reinterpret_cast<unsigned long long *>(partials) + i, CGX_RLX_AGENT));
-        s = block_sum<WAVES>(s, lds);
-        if (threadIdx.x == 0) {
-            *out = s;
-            __hip_atomic_store(counter, 0u, CGX_RLX_AGENT);
-        }
-    }
-}
-
 enum { kPlain = 0, kFusedSingle = 1 };   // the fused form always reads the replicated, contiguous r
 
 template <bool NT>
@@ -138,17 +102,25 @@ __device__ __forceinline__ double sum_ranks(const double *__restrict__ gathered,
     return s;
 }
 
-// Tail of iteration k-1, evaluated redundantly (and identically) by every thread of K1(k).
+// Tail of iteration k-1, evaluated redundantly (and identically) by every workgroup of K1(k).
+// r.r = fixed-order fold of K3's per-workgroup partials (the tail of the replicated-r segment): every
+// workgroup of every rank folds the same values the same way, so the break decision is the same everywhere,
+// and no in-kernel grid reduction (ticket + fences, ~4 us at the end of K3) is needed.  In K1 this sits
+// behind the first trip's HBM loads, which are already in flight.
 struct IterHead {
     double beta;
     bool stop;
 };
 
-__device__ __forceinline__ IterHead iteration_head(Scalars *sc, const SegView &sv, int k, double tol)
+template <int WAVES>
+__device__ __forceinline__ IterHead iteration_head(Scalars *sc, const SegView &sv, int k, double tol, double *lds)
 {
     IterHead h{0.0, false};
-    const double rsnew = seg_sum_slot(sv, kSlotRr);                  // MPI_Allreduce, cg.cc:117 (k==0: cg.cc:92)
-    const bool first = (blockIdx.x == 0 && threadIdx.x == 0);
+    double v = 0.0;
+    const int nparts = sv.S - sv.Sr;
+    for (int t = threadIdx.x; t < nparts; t += WAVES * 64) v += sv.base[sv.Sr + t];
+    const double rsnew = block_sum<WAVES>(v, lds);                   // r.r over all rows, cg.cc:116-117 (k==0: cg.cc:91-92)
+    const bool first = (blockIdx.x == 0 && threadIdx.x == 0) && !sc->done;   // nothing is written once converged
     if (k == 0) {                                                    // p = r (cg.cc:85): beta = 0, p_old = 0
         if (first) { sc->rs[0] = rsnew; sc->rs[1] = rsnew; }
         return h;
@@ -193,37 +165,34 @@ __device__ __forceinline__ d2 make_p(const SegView &sv, double beta, d2 p_old, i
 // FUSED: the vector is p_new = r + beta p_old, formed in registers from two L2-resident streams; the
 // workgroup whose turn it is (step index mod grid) also stores it, so p_new is written exactly once.
 // ------------------------------------------------------------------------------------------------
+// The default shape (8,2) is held to 128 VGPRs = 4 workgroups per CU (the 4096-workgroup grid of N=32768 then runs in
+// exactly 4 rounds; at 3 per CU it needs 5.33 and loses ~1.2 %, measured).
 template <int R, int U, int WAVES, int MODE>
-__global__ __launch_bounds__(WAVES * 64) void k_gemv_colsplit(const double *__restrict__ A, long lda, int rows,
+__global__ __launch_bounds__(WAVES * 64, ((R == 8 && U == 2) ? 4 : 1)) void k_gemv_colsplit(const double *__restrict__ A, long lda, int rows,
                                                                int row0_global, const double *__restrict__ v,
                                                                double *__restrict__ p_new, SegView sv,
                                                                double *__restrict__ Ap, double *partials,
                                                                Scalars *sc, int k, double tol)
 {
     constexpr bool FUSED = MODE != kPlain;
-    constexpr bool SINGLE = MODE == kFusedSingle;
     constexpr bool NT = true;   // A is streamed once: non-temporal loads keep p and r in L2 (+12 % measured)
-    double beta = 0.0;
-    if constexpr (FUSED) {
-        if (sc->done) return;   // converged earlier: the whole grid drains immediately
-        const IterHead h = iteration_head(sc, sv, k, tol);
-        if (h.stop) return;
-        beta = h.beta;
-    }
     __shared__ double red[WAVES][R];
 
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const long row0 = (long)blockIdx.x * R;
-    const int ncols = (int)lda;   // pad columns hold zeros in A and in the vector
+    const int ncols = (int)lda;   // pad columns hold zeros in A and in the vectors
+    const double *rfull = sv.base;   // FUSED: the replicated r, contiguous and zero padded up to lda
 
-    const double *a[R];
+    // Row bases are workgroup-uniform (SGPR pairs); the lane's position is ONE 32-bit byte offset, so each A load
+    // is `global_load_dwordx4 v, v_off, s[base]` and the R row pointers cost no vector registers.
+    const char *a[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) {
         long row = row0 + r;
         if (row > rows - 1) row = rows - 1;   // tail workgroup: re-read the last row, result discarded
         if (row < 0) row = 0;                 // shard without rows (N < P): stream the dummy row, store nothing
-        a[r] = A + row * lda;
+        a[r] = reinterpret_cast<const char *>(A + row * lda);
     }
     double acc0[R], acc1[R];
 #pragma unroll
@@ -233,57 +202,88 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_colsplit(const double *__re
     int c = w * 128 + lane * 2;
     int step = 0;                        // index of the step this trip starts with
     int my_step = (int)blockIdx.x;       // next step whose p_new this workgroup stores
-    for (; c + (U - 1) * kStep < ncols; c += U * kStep, step += U) {
-        d2 pv[U];
-        d2 av[U][R];
+    double beta = 0.0;
+
+    d2 pv[U], rv2[U];
+    d2 av[U][R];
+    // one trip = U steps: all vector and A loads first (R*U + 2U independent 16-B loads in flight per lane) ...
+    auto load_trip = [&](int cc) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) pv[u] = *reinterpret_cast<const d2 *>(v + c + u * kStep);
-        if constexpr (FUSED) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) pv[u] = make_p<SINGLE>(sv, beta, pv[u], c + u * kStep);
+        for (int u = 0; u < U; ++u) {
+            const unsigned off = (unsigned)(cc + u * kStep) * 8u;   // uniform base + 32-bit lane offset
+            pv[u] = *reinterpret_cast<const d2 *>(reinterpret_cast<const char *>(v) + off);
+            if constexpr (FUSED) rv2[u] = *reinterpret_cast<const d2 *>(reinterpret_cast<const char *>(rfull) + off);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
-            for (int r = 0; r < R; ++r) av[u][r] = load_a<NT>(a[r] + c + u * kStep);
-        // Keep all R*U loads in flight: without this fence hipcc's occupancy-driven scheduler
-        // re-serialises them as load / s_waitcnt vmcnt(0) / fma pairs (measured in the .s).
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (FUSED) {
+            for (int r = 0; r < R; ++r)
+                av[u][r] = load_a<NT>(reinterpret_cast<const double *>(a[r] + (unsigned)(cc + u * kStep) * 8u));
+    };
+    // ... then p = r + beta p_old (cg.cc:127-129), its one store, and the FMAs.
+    auto compute_trip = [&](int cc, int st) {
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (step + u == my_step) {
-                    *reinterpret_cast<d2 *>(p_new + c + u * kStep) = pv[u];
+        for (int u = 0; u < U; ++u) {
+            if constexpr (FUSED) {
+                pv[u].x = fma(beta, pv[u].x, rv2[u].x);
+                pv[u].y = fma(beta, pv[u].y, rv2[u].y);
+                if (st + u == my_step) {
+                    *reinterpret_cast<d2 *>(reinterpret_cast<char *>(p_new) + (unsigned)(cc + u * kStep) * 8u) = pv[u];
                     my_step += (int)gridDim.x;
                 }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
+            }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 acc0[r] = fma(av[u][r].x, pv[u].x, acc0[r]);
                 acc1[r] = fma(av[u][r].y, pv[u].y, acc1[r]);
             }
+        }
+    };
+
+    // The first trip's loads do not depend on the iteration head (done / r.r / beta): issue them first, so the
+    // head's dependent loads and its block reduction overlap the first HBM round trip instead of preceding it.
+    // Only for the light shapes: with R*U = 16 the 80 extra live registers push the kernel past 128 VGPRs
+    // (3 workgroups per CU: the 4096-workgroup grid of N=32768 then runs 5.33 rounds instead of 4, -1.2 %).
+    constexpr bool HOIST = R * U <= 8;
+    const bool first = HOIST && c + (U - 1) * kStep < ncols;
+    if (first) load_trip(c);
+    if constexpr (FUSED) {
+        __shared__ double head_lds[WAVES];
+        const int done = sc->done;       // converged earlier: the whole grid drains immediately
+        const IterHead h = iteration_head<WAVES>(sc, sv, k, tol, head_lds);
+        if (done || h.stop) return;
+        beta = h.beta;
+    }
+    // Keep all loads of a trip in flight: without this fence hipcc's occupancy-driven scheduler
+    // re-serialises them as load / s_waitcnt vmcnt(0) / fma pairs (measured in the .s).
+    __builtin_amdgcn_sched_barrier(0);
+    if (first) {
+        compute_trip(c, step);
+        c += U * kStep;
+        step += U;
+    }
+    for (; c + (U - 1) * kStep < ncols; c += U * kStep, step += U) {
+        load_trip(c);
+        __builtin_amdgcn_sched_barrier(0);
+        compute_trip(c, step);
     }
     for (; c < ncols; c += kStep, ++step) {   // remaining single steps (lda is even, so c+1 < lda)
-        d2 pv = *reinterpret_cast<const d2 *>(v + c);
+        d2 p1 = *reinterpret_cast<const d2 *>(v + c);
         if constexpr (FUSED) {
-            pv = make_p<SINGLE>(sv, beta, pv, c);
+            const d2 r1 = *reinterpret_cast<const d2 *>(rfull + c);
+            p1.x = fma(beta, p1.x, r1.x);
+            p1.y = fma(beta, p1.y, r1.y);
             if (step == my_step) {
-                *reinterpret_cast<d2 *>(p_new + c) = pv;
+                *reinterpret_cast<d2 *>(p_new + c) = p1;
                 my_step += (int)gridDim.x;
             }
         }
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            d2 av = load_a<NT>(a[r] + c);
-            acc0[r] = fma(av.x, pv.x, acc0[r]);
-            acc1[r] = fma(av.y, pv.y, acc1[r]);
+            d2 a1 = load_a<NT>(reinterpret_cast<const double *>(a[r] + (unsigned)c * 8u));
+            acc0[r] = fma(a1.x, p1.x, acc0[r]);
+            acc1[r] = fma(a1.y, p1.y, acc1[r]);
         }
-    }
-    if constexpr (FUSED) {
-        // steps past this workgroup's last column (possible only for lanes beyond lda): nothing to store.
-        // Steps owned by workgroups that do not exist cannot occur: my_step walks all residues mod grid.
     }
 
 #pragma unroll
@@ -334,9 +334,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_ldsp(const double *__restri
     constexpr bool NT = true;
     double beta = 0.0;
     if constexpr (FUSED) {
-        if (sc->done) return;
-        const IterHead h = iteration_head(sc, sv, k, tol);
-        if (h.stop) return;
+        __shared__ double head_lds[WAVES];
+        const int done = sc->done;
+        const IterHead h = iteration_head<WAVES>(sc, sv, k, tol, head_lds);
+        if (done || h.stop) return;
         beta = h.beta;
     }
     constexpr int TILE = 2048;                       // doubles of the vector per LDS buffer (16 KiB)
@@ -467,43 +468,46 @@ __global__ __launch_bounds__(256) void k_update_xr(int n, int rows, int row0, co
                                                     double *__restrict__ x, SegView rv, Scalars *sc, int parity,
                                                     double *partials)
 {
-    if (sc->done) return;
     __shared__ double lds[4];
-    __shared__ int s_flag;
     double *r = rv.base;
+    // Issue every load this thread needs before the first wait: the kernel is a chain of ~1 us memory round
+    // trips (flag, partials, vectors), so they are overlapped instead of serialised.
+    const int done = sc->done;
     const double rsold = sc->rs[parity];
+    const int i = blockIdx.x * 256 + threadIdx.x;                     // global row
+    const int li = i - row0;
+    const bool in = i < n, own = in && li >= 0 && li < rows;
+    double ap_i = 0.0, r_i = 0.0, p_i = 0.0, x_i = 0.0;
+    if (in) { ap_i = seg_load(apv, i); r_i = r[i]; }
+    if (own) { p_i = p_new[i]; x_i = x[li]; }
     // p.Ap = sum of every K1 workgroup partial of every rank (cblas_ddot + MPI_Allreduce, cg.cc:105-106), folded
     // in one fixed order by every workgroup of every rank: bit-identical everywhere.
     double cs = 0.0;
     const int total = apv.nranks * tail_count;
-    for (int i = threadIdx.x; i < total; i += 256) {
-        const int q = i / tail_count, j = i - q * tail_count;
+    for (int t = threadIdx.x; t < total; t += 256) {
+        const int q = t / tail_count, j = t - q * tail_count;
         cs += apv.base[(long)q * apv.S + apv.Sr + tail_off + j];
     }
+    if (done) return;   // converged earlier (uniform over the grid): nothing is written
     const double conj = block_sum<4>(cs, lds);
     const double alpha = rsold / fmax(conj, rsold * kNearZero);      // cg.cc:107
-    const int i = blockIdx.x * 256 + threadIdx.x;                     // global row
     double rr = 0.0;
-    if (i < n) {
-        const double apv_i = seg_load(apv, i);
-        const double rn = fma(-alpha, apv_i, r[i]);                   // cg.cc:113, for every row (r is replicated)
+    if (in) {
+        const double rn = fma(-alpha, ap_i, r_i);                     // cg.cc:113, for every row (r is replicated)
         r[i] = rn;
         rr = rn * rn;                                                 // cg.cc:116
-        const int li = i - row0;
-        if (li >= 0 && li < rows) x[li] = fma(alpha, p_new[i], x[li]);   // cg.cc:110, own rows only
     }
+    if (own) x[li] = fma(alpha, p_i, x_i);                            // cg.cc:110, own rows only
     rr = block_sum<4>(rr, lds);
-    grid_sum_last_arriver<4>(rr, partials, &sc->counter[1], r + rv.Sr + kSlotRr, lds, &s_flag);
+    if (threadIdx.x == 0) r[rv.Sr + blockIdx.x] = rr;   // one r.r partial per workgroup, folded by the next K1's head
 }
 
-// Loop ran out after k iterations: the tail of iteration k-1 that the next K1 would have done.
-__global__ void k_close_iteration(Scalars *sc, SegView sv, int k, double tol)
+// Loop ran out after k iterations: the tail of iteration k-1 that the next K1 would have done (same code,
+// same bits), or, for k == 0, the rsold of cg.cc:91-92.
+__global__ __launch_bounds__(256) void k_close_iteration(Scalars *sc, SegView sv, int k, double tol)
 {
-    if (blockIdx.x != 0 || threadIdx.x != 0 || sc->done) return;
-    const double rsnew = seg_sum_slot(sv, kSlotRr);                  // cg.cc:117 (k == 0: cg.cc:92)
-    if (k == 0) { sc->rs[0] = rsnew; sc->rs[1] = rsnew; return; }    // no iteration ran: only rsold exists
-    sc->rs[k & 1] = rsnew;                                           // cg.cc:132
-    if (sqrt(rsnew) < tol) { sc->k_final = k - 1; sc->done = 1; }    // cg.cc:120-121
+    __shared__ double lds[4];
+    (void)iteration_head<4>(sc, sv, k, tol, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -538,7 +542,7 @@ __global__ __launch_bounds__(256) void k_init_residual(int n, const double *__re
         rr = rvv * rvv;                                    // rsold = r.p with p == r, cg.cc:85,91
     }
     rr = block_sum<4>(rr, lds);
-    if (threadIdx.x == 0) partials[blockIdx.x] = rr;
+    if (threadIdx.x == 0) r[rv.Sr + blockIdx.x] = rr;   // same slots as K3's partials: K1(0) folds them (cg.cc:91-92)
 }
 
 __global__ __launch_bounds__(256) void k_unpack_segments(SegView sv, double *__restrict__ v_full, long lda)
@@ -844,7 +848,7 @@ hipError_t launch_update_xr(int n, int rows, int row0, const double *p_new, SegV
 
 hipError_t launch_close_iteration(Scalars *sc, SegView seg, int k, double tol, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_close_iteration, dim3(1), dim3(64), 0, s, sc, seg, k, tol);
+    hipLaunchKernelGGL(k_close_iteration, dim3(1), dim3(256), 0, s, sc, seg, k, tol);
     return hipGetLastError();
 }
 

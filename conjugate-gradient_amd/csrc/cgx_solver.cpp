@@ -275,12 +275,13 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
         HIP_TRY(ctx, hipMalloc(&s.p[0], (size_t)ctx->lda * sizeof(double)));
         HIP_TRY(ctx, hipMalloc(&s.p[1], (size_t)ctx->lda * sizeof(double)));
         const size_t apg_bytes = (size_t)ctx->nranks * ctx->seg_S * sizeof(double);
-        const size_t rbuf_bytes = (size_t)(ctx->lda + cgx::kSlots) * sizeof(double);
+        const int rr_parts = cgx::update_xr_grid(n);   // one r.r partial per K3 workgroup
+        const size_t rbuf_bytes = (size_t)(ctx->lda + rr_parts) * sizeof(double);
         HIP_TRY(ctx, hipMalloc(&s.apg, apg_bytes));
         HIP_TRY(ctx, hipMalloc(&s.rbuf, rbuf_bytes));
         s.apv = cgx::SegView{s.apg, ctx->seg_S, ctx->seg_Sr, n / ctx->nranks, ctx->nranks, n, s.rank, 0, 0, 0};
         cgx::seg_finalize(&s.apv);
-        s.rv = cgx::SegView{s.rbuf, (int)ctx->lda + cgx::kSlots, (int)ctx->lda, n, 1, n, 0, 0, 0, 0};
+        s.rv = cgx::SegView{s.rbuf, (int)ctx->lda + rr_parts, (int)ctx->lda, n, 1, n, 0, 0, 0, 0};
         cgx::seg_finalize(&s.rv);
         HIP_TRY(ctx, hipMalloc(&s.partials, (size_t)s.npartials * sizeof(double)));
         HIP_TRY(ctx, hipMalloc(&s.sc, sizeof(Scalars)));
@@ -909,7 +910,7 @@ cgx_status cgx_solve_begin(cgx_ctx *ctx, const double *x0)
     for (auto &s : ctx->shards) {
         HIP_TRY(ctx, hipMemsetAsync(s.sc, 0, sizeof(Scalars), st));
         HIP_TRY(ctx, hipMemsetAsync(s.apg, 0, (size_t)ctx->nranks * ctx->seg_S * sizeof(double), st));
-        HIP_TRY(ctx, hipMemsetAsync(s.rbuf, 0, (size_t)(ctx->lda + cgx::kSlots) * sizeof(double), st));
+        HIP_TRY(ctx, hipMemsetAsync(s.rbuf, 0, (size_t)s.rv.S * sizeof(double), st));
         // x (initial guess) replicated for the first GEMV, x_sub = x[rows]  (cg.cc:72, 80)
         HIP_TRY(ctx, hipMemcpyAsync(s.p[0], x0, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
         if (s.rows > 0)
@@ -919,9 +920,6 @@ cgx_status cgx_solve_begin(cgx_ctx *ctx, const double *x0)
     CGX_TRY(gather_segments(ctx, false));
     for (auto &s : ctx->shards)
         HIP_TRY(ctx, cgx::launch_init_residual(n, s.b_full, s.apv, s.rv, s.partials, st));           // cg.cc:82
-    for (auto &s : ctx->shards)
-        HIP_TRY(ctx, cgx::launch_reduce_partials(s.partials, cgx::update_xr_grid(n),
-                                                 s.rbuf + ctx->lda + cgx::kSlotRr, st));             // cg.cc:91-92
     for (auto &s : ctx->shards) {
         // p_old of iteration 0 is 0, so K1(0) forms p = r + 0*0 = r  (p_sub = r_sub, cg.cc:85)
         HIP_TRY(ctx, hipMemsetAsync(s.p[0], 0, vec_bytes, st));
@@ -1104,14 +1102,14 @@ cgx_status cgx_probe_vector_ops(cgx_ctx *ctx, int n, double alpha, double beta, 
     HIP_TRY(ctx, hipMalloc(&dp0, vbytes));
     HIP_TRY(ctx, hipMalloc(&dp1, vbytes));
     HIP_TRY(ctx, hipMalloc(&dap, (size_t)S * sizeof(double)));
-    HIP_TRY(ctx, hipMalloc(&drb, (size_t)(lda + cgx::kSlots) * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc(&drb, (size_t)(lda + grid) * sizeof(double)));
     HIP_TRY(ctx, hipMalloc(&dpart, (size_t)(grid + 8) * sizeof(double)));
     HIP_TRY(ctx, hipMalloc(&dA, vbytes));
     HIP_TRY(ctx, hipMalloc(&dAp1, 64 * sizeof(double)));
     HIP_TRY(ctx, hipMalloc(&dsc, sizeof(Scalars)));
     cgx::SegView apv{dap, S, Sr, n, 1, n, 0, 0, 0, 0};
     cgx::seg_finalize(&apv);
-    cgx::SegView rv{drb, (int)lda + cgx::kSlots, (int)lda, n, 1, n, 0, 0, 0, 0};
+    cgx::SegView rv{drb, (int)lda + grid, (int)lda, n, 1, n, 0, 0, 0, 0};
     cgx::seg_finalize(&rv);
     // Force the wanted alpha: with rsold = alpha and p.Ap = 1, K3 computes alpha / max(1, alpha*1e-14) = alpha.
     Scalars hs{};
@@ -1120,7 +1118,7 @@ cgx_status cgx_probe_vector_ops(cgx_ctx *ctx, int n, double alpha, double beta, 
     HIP_TRY(ctx, hipMemsetAsync(dp0, 0, vbytes, st));
     HIP_TRY(ctx, hipMemsetAsync(dp1, 0, vbytes, st));
     HIP_TRY(ctx, hipMemsetAsync(dap, 0, (size_t)S * sizeof(double), st));
-    HIP_TRY(ctx, hipMemsetAsync(drb, 0, (size_t)(lda + cgx::kSlots) * sizeof(double), st));
+    HIP_TRY(ctx, hipMemsetAsync(drb, 0, (size_t)(lda + grid) * sizeof(double), st));
     HIP_TRY(ctx, hipMemsetAsync(dA, 0, vbytes, st));
     HIP_TRY(ctx, hipMemcpyAsync(dsc, &hs, sizeof hs, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(dx, x, bytes, hipMemcpyHostToDevice, st));
@@ -1129,14 +1127,17 @@ cgx_status cgx_probe_vector_ops(cgx_ctx *ctx, int n, double alpha, double beta, 
     HIP_TRY(ctx, hipMemcpyAsync(dap, Ap, bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemcpyAsync(dap + Sr, &one, sizeof(double), hipMemcpyHostToDevice, st));   // the one p.Ap "partial"
     HIP_TRY(ctx, cgx::launch_update_xr(n, n, 0, dp0, apv, 0, 1, dx, rv, dsc, 0, dpart, st));
-    double rr_host = 0.0;
-    HIP_TRY(ctx, hipMemcpyAsync(&rr_host, drb + lda + cgx::kSlotRr, sizeof(double), hipMemcpyDeviceToHost, st));
+    std::vector<double> rr_parts_h((size_t)grid);
+    HIP_TRY(ctx, hipMemcpyAsync(rr_parts_h.data(), drb + lda, (size_t)grid * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(x, dx, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipMemcpyAsync(r, drb, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    // Force the wanted beta: rsold = 1, r.r = beta  =>  K1(k=1) computes beta/1.
+    double rr_host = 0.0;
+    for (double v : rr_parts_h) rr_host += v;
+    // Force the wanted beta: rsold = 1, the r.r partials = {beta, 0, ...}  =>  K1(k=1) computes beta/1.
     HIP_TRY(ctx, hipMemcpyAsync(&dsc->rs[0], &one, sizeof(double), hipMemcpyHostToDevice, st));
-    HIP_TRY(ctx, hipMemcpyAsync(drb + lda + cgx::kSlotRr, &beta, sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemsetAsync(drb + lda, 0, (size_t)grid * sizeof(double), st));
+    HIP_TRY(ctx, hipMemcpyAsync(drb + lda, &beta, sizeof(double), hipMemcpyHostToDevice, st));
     cgx::GemvPlan plan = cgx::plan_gemv(ctx->cfg.gemv_variant, 1, (int)lda);
     HIP_TRY(ctx, cgx::launch_gemv_fused(plan, dA, lda, 1, 0, dp0, dp1, rv, dAp1, dAp1 + 8, dsc, 1, -1.0 /* never converges */, st));
     HIP_TRY(ctx, hipMemcpyAsync(p, dp1, bytes, hipMemcpyDeviceToHost, st));
