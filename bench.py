@@ -45,8 +45,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-gemv", action="store_true", help="do not bracket K1 with HIP events")
     ap.add_argument("--profile-every", type=int, default=0,
-                    help="event-time every n-th K1 launch (default: 1 on one GPU, 8 on several: the event pair "
-                         "costs ~10 us per timed launch)")
+                    help="event-time every n-th K1 launch (default: 4 on one GPU, 8 on several: the event pair "
+                         "costs ~5 us per timed launch, measured)")
     return ap.parse_args()
 
 
@@ -134,7 +134,7 @@ def main():
         n = int(math.floor(16384 * math.sqrt(world)))   # code/MPI/cg.run:22-44 rounding rule, N^2/P constant
     else:
         n = 32768
-    profile_every = 0 if args.no_profile_gemv else (args.profile_every or (1 if world == 1 else 8))
+    profile_every = 0 if args.no_profile_gemv else (args.profile_every or (4 if world == 1 else 8))
 
     def all_ok(flag):
         """True only if `flag` is true on every rank (so that all ranks take the same branch)."""
