@@ -38,8 +38,9 @@ def parse_args():
     ap.add_argument("--matrix-size", dest="n", type=int, default=0, help="matrix size (default 32768; weak mode: floor(16384*sqrt(P)))")
     ap.add_argument("--mode", choices=["strong", "weak"], default="strong")
     ap.add_argument("--variant", type=int, default=0, help="K1 shape override (DESIGN.md)")
-    ap.add_argument("--transport", choices=["auto", "p2p", "rccl"], default="auto",
-                    help="multi-GPU exchange: direct xGMI mailboxes (p2p), RCCL, or p2p with RCCL as fallback (auto)")
+    ap.add_argument("--transport", choices=["auto", "p2p", "p2p-sep", "rccl"], default="auto",
+                    help="multi-GPU exchange: direct xGMI mailboxes with the exchange folded into K3 (p2p) or as its own "
+                         "kernel (p2p-sep), RCCL, or whichever of those works and calibrates fastest on this node (auto)")
     ap.add_argument("--lda-pad", type=int, default=-1)
     ap.add_argument("--cpu-baseline-iters", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -165,7 +166,7 @@ def main():
                 uid = broadcast_bytes(dist, pkg.comm_unique_id() if rank == 0 else None, pkg.cgx.UNIQUE_ID_BYTES, ctl)
                 s = pkg.CGSolver(comm_mode=pkg.COMM_RCCL, unique_id=uid, **common)
             else:
-                s = pkg.CGSolver(comm_mode=pkg.COMM_P2P, **common)
+                s = pkg.CGSolver(comm_mode=pkg.COMM_P2P, p2p_separate_exchange=(transport == "p2p-sep"), **common)
                 mine = torch.tensor(list(s.p2p_export()), dtype=torch.uint8, device=ctl)
                 allh = [torch.zeros_like(mine) for _ in range(world)]
                 dist.all_gather(allh, mine)          # every rank's mailbox handle to every rank
@@ -242,7 +243,7 @@ def main():
     if not use_comm:
         order = ["self"]
     elif args.transport == "auto":
-        order = ["p2p", "rccl"]
+        order = ["p2p", "p2p-sep", "rccl"]
     else:
         order = [args.transport]
     # Build every candidate transport that works on this node; with more than one, a short calibration run
@@ -307,8 +308,9 @@ def main():
                             "(BASELINE.json configs[%d])" % (n, 2 if world == 1 else (3 if args.mode == "strong" else 4)),
                 "n": n, "rows_per_gpu": rows0, "parallelism": "rowblock%d" % world,
                 "collectives": {"self": "none",
-                                "rccl": "2 x ncclAllGather per iteration (K1 partials; [r slice | r.r])",
-                                "p2p": "2 x mailbox all-gather kernel per iteration over IPC/xGMI (K1 partials; [r slice | r.r])"}[transport],
+                                "rccl": "1 x ncclAllGather per iteration ([Ap slice | p.Ap partials])",
+                                "p2p": "1 exchange per iteration over IPC/xGMI mailboxes, folded into K3 ([Ap slice | p.Ap])",
+                                "p2p-sep": "1 mailbox all-gather kernel per iteration over IPC/xGMI ([Ap slice | p.Ap])"}[transport],
                 "transport": transport,
                 "transport_calibration_ms_per_iteration": calib or None,
                 "k1_variant": args.variant,

@@ -32,7 +32,8 @@ class Config(C.Structure):
         ("struct_version", C.c_int), ("comm_mode", C.c_int), ("device", C.c_int), ("rank", C.c_int),
         ("nranks", C.c_int), ("unique_id", C.c_ubyte * UNIQUE_ID_BYTES), ("gemv_variant", C.c_int),
         ("lda_pad", C.c_int), ("check_every", C.c_int), ("profile_gemv", C.c_int), ("use_graph", C.c_int),
-        ("p2p_mailbox_kib", C.c_int), ("p2p_timeout_ms", C.c_int), ("reserved", C.c_int * 6),
+        ("p2p_mailbox_kib", C.c_int), ("p2p_timeout_ms", C.c_int), ("p2p_separate_exchange", C.c_int),
+        ("reserved", C.c_int * 5),
     ]
 
 
@@ -143,7 +144,8 @@ class CGSolver:
     """
 
     def __init__(self, comm_mode=COMM_SELF, nranks=1, rank=0, device=0, unique_id=None, gemv_variant=0,
-                 lda_pad=-1, check_every=0, profile_gemv=False, p2p_timeout_ms=0, p2p_mailbox_kib=0):
+                 lda_pad=-1, check_every=0, profile_gemv=False, p2p_timeout_ms=0, p2p_mailbox_kib=0,
+                 p2p_separate_exchange=False):
         L = lib()
         cfg = Config()
         L.cgx_config_init(C.byref(cfg))
@@ -157,6 +159,7 @@ class CGSolver:
         cfg.profile_gemv = int(profile_gemv)   # n > 0: every n-th K1 launch is event-timed
         cfg.p2p_timeout_ms = p2p_timeout_ms
         cfg.p2p_mailbox_kib = p2p_mailbox_kib
+        cfg.p2p_separate_exchange = 1 if p2p_separate_exchange else 0
         if unique_id is not None:
             assert len(unique_id) == UNIQUE_ID_BYTES
             C.memmove(cfg.unique_id, bytes(unique_id), UNIQUE_ID_BYTES)

@@ -122,6 +122,13 @@ hipError_t launch_mailbox_allgather(const MailboxView &mv, int chan, unsigned lo
                                     int count, int tail_off, int tail_n, double *dst, long dst_stride, int sum_off,
                                     int copy_self, long long timeout_ticks, int *err, hipStream_t s);
 
+// K3 with the iteration's exchange inside (CGX_COMM_P2P): workgroups 0..P-1 push [Ap slice | folded partial] to
+// their peer, every workgroup waits (bounded) for all flags and reads the Ap element of its row and the P scalars
+// straight from the mailbox.  The iteration is then K1 + this kernel.
+hipError_t launch_update_xr_p2p(int n, int rows, int row0, const double *p_new, SegView apv, int npart,
+                                const MailboxView &mv, int chan, unsigned long long epoch, double *x, SegView rv, Scalars *sc,
+                                int parity, long long timeout_ticks, int *err, hipStream_t s);
+
 // Loopback "collective": copy local[kSlots] of every shard into gathered[] of every shard (<= 16 shards).
 hipError_t launch_loopback_gather(double *const *gathered_ptrs, const Scalars *const *scalar_ptrs, int nshards,
                                   hipStream_t s);

@@ -720,6 +720,101 @@ __global__ __launch_bounds__(256) void k_mailbox_allgather(MailboxView mv, int c
 }
 
 // ------------------------------------------------------------------------------------------------
+// K3 with the exchange inside (CGX_COMM_P2P): iteration = K1 + this kernel, nothing else.
+// Workgroups 0..P-1 first push [Ap slice | folded p.Ap partial] into their peer's mailbox (same protocol as
+// k_mailbox_allgather); then EVERY workgroup waits (bounded) for all peers' flags and reads what it needs
+// straight from the mailbox slots with system-scope loads: the P scalars and, per thread, the one Ap element of
+// its row.  No copy-out pass, no kernel boundary between exchange and update.  All workgroups of the grid are
+// co-resident (n/256 <= a few hundred workgroups, nothing else runs on the device), so the pushers always make
+// progress while the others poll.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_update_xr_p2p(int n, int rows, int row0, const double *__restrict__ p_new,
+                                                        SegView apv, int npart, MailboxView mv, int chan,
+                                                        unsigned long long epoch, double *__restrict__ x, SegView rv,
+                                                        Scalars *sc, int parity_rs, long long timeout_ticks, int *err)
+{
+    __shared__ double lds[4];
+    __shared__ double s_sums[kMaxRanks];
+    double *r = rv.base;
+    const int tid = threadIdx.x, P = mv.nranks, me = mv.rank;
+    const int done = sc->done;
+    const int had_err = *reinterpret_cast<volatile int *>(err);
+    const double rsold = sc->rs[parity_rs];
+    const int i = blockIdx.x * 256 + tid;   // global row
+    const int li = i - row0;
+    const bool in = i < n, own = in && li >= 0 && li < rows;
+    double r_i = 0.0, p_i = 0.0, x_i = 0.0;
+    if (in) r_i = r[i];
+    if (own) { p_i = p_new[i]; x_i = x[li]; }
+    const double *mine = apv.base + (long)me * apv.S;   // my segment: [Ap slice | npart partials]
+    double v = 0.0;
+    for (int t = tid; t < npart; t += 256) v += mine[apv.Sr + t];
+    // `done` is identical on every rank (r.r is bit-identical), so either all ranks exchange or none does
+    if (__syncthreads_or(done | had_err)) return;
+    const double my_sum = block_sum<4>(v, lds);         // local half of MPI_Allreduce(p.Ap), cg.cc:105-106
+
+    const int par = (int)(epoch & 1);
+    const long slot = mv.slot_bytes[chan];
+    for (int peer = blockIdx.x; peer < P; peer += gridDim.x) {
+        if (peer == me) continue;
+        double *out = reinterpret_cast<double *>(mv.base[peer] + mv.data_off[chan] + ((long)par * P + me) * slot);
+        const int pairs = apv.Sr >> 1;   // Sr is even
+        for (int t = tid; t < pairs; t += 256)
+            *reinterpret_cast<d2 *>(out + 2 * t) = *reinterpret_cast<const d2 *>(mine + 2 * t);
+        if (tid == 0) out[apv.Sr] = my_sum;
+        __threadfence_system();   // release
+        __syncthreads();
+        if (tid == 0)
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(mv.base[peer] + ((long)chan * kMaxRanks + me) * kP2pFlagStride),
+                               epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // every workgroup: lane q waits for peer q's flag in MY mailbox (bounded by the 100 MHz wall clock)
+    int ok = 1;
+    if (tid < P && tid != me) {
+        const unsigned long long *flag = reinterpret_cast<const unsigned long long *>(
+            mv.base[me] + ((long)chan * kMaxRanks + tid) * kP2pFlagStride);
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+            __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t0 > timeout_ticks) {
+                ok = 0;
+                atomicExch(err, 1);
+                break;
+            }
+        }
+    }
+    if (!__syncthreads_and(ok)) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope
+    const unsigned long long *box = reinterpret_cast<const unsigned long long *>(mv.base[me] + mv.data_off[chan]);
+    const long slot_w = slot / 8;
+    if (tid < P)
+        s_sums[tid] = (tid == me) ? my_sum
+                                  : __longlong_as_double((long long)__hip_atomic_load(
+                                        box + ((long)par * P + tid) * slot_w + apv.Sr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    double ap_i = 0.0;
+    if (in) {
+        const int q = (P > 1) ? seg_owner(apv, i) : 0;
+        const int off = i - q * apv.n_loc;
+        ap_i = (q == me) ? mine[off]
+                         : __longlong_as_double((long long)__hip_atomic_load(box + ((long)par * P + q) * slot_w + off,
+                                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    }
+    __syncthreads();
+    double conj = s_sums[0];
+    for (int q = 1; q < P; ++q) conj += s_sums[q];                   // rank order: bit-identical on every rank (cg.cc:106)
+    const double alpha = rsold / fmax(conj, rsold * kNearZero);      // cg.cc:107
+    double rr = 0.0;
+    if (in) {
+        const double rn = fma(-alpha, ap_i, r_i);                     // cg.cc:113
+        r[i] = rn;
+        rr = rn * rn;                                                 // cg.cc:116
+    }
+    if (own) x[li] = fma(alpha, p_i, x_i);                            // cg.cc:110
+    rr = block_sum<4>(rr, lds);
+    if (tid == 0) r[rv.Sr + blockIdx.x] = rr;
+}
+
+// ------------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------------
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
@@ -843,6 +938,15 @@ hipError_t launch_update_xr(int n, int rows, int row0, const double *p_new, SegV
 {
     hipLaunchKernelGGL(k_update_xr, dim3(update_xr_grid(n)), dim3(256), 0, s, n, rows, row0, p_new, apv, tail_off,
                        tail_count, x, rv, sc, parity, partials);
+    return hipGetLastError();
+}
+
+hipError_t launch_update_xr_p2p(int n, int rows, int row0, const double *p_new, SegView apv, int npart,
+                                const MailboxView &mv, int chan, unsigned long long epoch, double *x, SegView rv, Scalars *sc,
+                                int parity, long long timeout_ticks, int *err, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_update_xr_p2p, dim3(update_xr_grid(n)), dim3(256), 0, s, n, rows, row0, p_new, apv, npart, mv, chan,
+                       epoch, x, rv, sc, parity, timeout_ticks, err);
     return hipGetLastError();
 }
 

@@ -436,6 +436,15 @@ cgx_status enqueue_iteration(cgx_ctx *ctx, int k)
     hipStream_t st = ctx->stream;
     // tail of iteration k-1 (cg.cc:117-132) + GEMV and p.Ap partials of iteration k (cg.cc:100-105)
     for (auto &s : ctx->shards) CGX_TRY(run_gemv_fused(ctx, s, k));
+    if (ctx->cfg.comm_mode == CGX_COMM_P2P && ctx->nranks > 1 && !ctx->cfg.p2p_separate_exchange) {
+        // direct peer exchange folded into K3: the iteration is two kernels, no collective launch at all
+        Shard &s = ctx->shards[0];
+        if (!ctx->p2p_ready) return fail(ctx, CGX_ERR_P2P, "cgx_p2p_import has not been called");
+        const unsigned long long epoch = ++ctx->p2p_epoch[1];
+        HIP_TRY(ctx, cgx::launch_update_xr_p2p(ctx->n, s.rows, s.row0, s.p[(k + 1) & 1], s.apv, ctx->npart, ctx->mv, 1, epoch,
+                                               s.x, s.rv, s.sc, k & 1, ctx->p2p_timeout_ticks, ctx->d_p2p_err, st));
+        return CGX_OK;
+    }
     CGX_TRY(gather_segments(ctx, true));                                                             // cg.cc:106
     const bool folded = ctx->cfg.comm_mode == CGX_COMM_P2P;   // the exchange kernel already folded each rank's partials
     for (auto &s : ctx->shards)
@@ -555,6 +564,7 @@ cgx_status cgx_create(cgx_ctx **out, const cgx_config *cfg_in)
     ctx->device = cfg.device;
     ctx->nranks = cfg.nranks;
     if (ctx->cfg.check_every <= 0) ctx->cfg.check_every = 16;
+    if (getenv("CGX_P2P_SEPARATE_EXCHANGE")) ctx->cfg.p2p_separate_exchange = 1;
 
     auto bail = [&](cgx_status st) {
         g_create_error = ctx->err;

@@ -67,7 +67,8 @@ typedef struct cgx_config {
     int  use_graph;           /* 1 = replay the iteration body from a hipGraph              */
     int  p2p_mailbox_kib;     /* CGX_COMM_P2P: mailbox size in KiB (0 = 4096)               */
     int  p2p_timeout_ms;      /* CGX_COMM_P2P: bound of every in-kernel wait (0 = 5000)     */
-    int  reserved[6];
+    int  p2p_separate_exchange; /* CGX_COMM_P2P: 1 = exchange in its own kernel between K1 and K3 (default 0: folded into K3) */
+    int  reserved[5];
 } cgx_config;
 
 typedef struct cgx_result {
