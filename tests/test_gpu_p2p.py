@@ -12,20 +12,23 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run(world, n, max_iter, tmp_path, port, variant=0):
+def run(world, n, max_iter, tmp_path, port, variant=0, separate=0):
     out = tmp_path / ("p2p_%d_%d.json" % (world, n))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "tests", "p2p_worker.py"), str(n), str(max_iter), str(out), str(variant)]
+           os.path.join(ROOT, "tests", "p2p_worker.py"), str(n), str(max_iter), str(out), str(variant), str(separate)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=420,
                        env=dict(os.environ, OMP_NUM_THREADS="1", MASTER_ADDR="127.0.0.1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     return json.load(open(out))
 
 
-@pytest.mark.parametrize("world,n,max_iter,port", [(2, 2048, 200, 29701), (4, 1000, 150, 29702), (3, 1024, 4000, 29703)])
-def test_p2p_processes_on_one_gpu(tmp_path, world, n, max_iter, port):
-    v = run(world, n, max_iter, tmp_path, port)
+@pytest.mark.parametrize("world,n,max_iter,port,separate", [
+    (2, 2048, 200, 29701, 0), (4, 1000, 150, 29702, 0), (3, 1024, 4000, 29703, 0),   # exchange folded into K3 (default)
+    (3, 1000, 150, 29704, 1), (2, 1024, 4000, 29705, 1),                             # exchange as its own kernel
+])
+def test_p2p_processes_on_one_gpu(tmp_path, world, n, max_iter, port, separate):
+    v = run(world, n, max_iter, tmp_path, port, separate=separate)
     assert v["selftest_ok"], v
     assert v["ranks_agree"], v
     assert v["k"] == v["k_oracle"] or (v["converged"] and abs(v["k"] - v["k_oracle"]) <= 0.15 * v["k_oracle"]), v
