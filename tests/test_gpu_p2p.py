@@ -49,3 +49,12 @@ def test_cgsolver_cli_forked_ranks_over_mailboxes(tmp_path):
     assert r.stdout.count("[STEP") == 1                                                 # only rank 0 prints (cg.cc:144)
     assert out.read_text().strip().startswith("2048,3,")
     assert "gpus=3" in r.stderr
+
+
+def test_p2p_config4_n32768_500_iterations_4_processes(tmp_path):
+    """BASELINE.json configs[3] shape (N=32768, 500 iterations, row blocks) with 4 real processes exchanging over
+    the mailboxes, against the reference's recorded residual, ||x|| and sampled x."""
+    v = run(4, 32768, 500, tmp_path, 29706)
+    assert v["selftest_ok"] and v["ranks_agree"], v
+    assert v["k"] == 500 and not v["converged"], v
+    assert v["residual_rel"] < 1e-6 and v["x_norm_rel"] < 1e-12 and v["dx"] < 1e-12, v
