@@ -6,19 +6,19 @@
 
 namespace cgx {
 
-// Scalar exchange: every shard publishes kSlots doubles; consumers sum slot v over ranks in rank order
-// (bit-identical on every shard, which is what makes all ranks take the same break, cg.cc:117-121).
+// Small scalar exchange of the verification phase (cg.cc:144-151): every shard publishes kSlots doubles, the
+// host sums slot v over ranks in rank order.
 constexpr int kSlots = 4;
-constexpr int kSlotConj = 0;   // p.Ap partial              (cg.cc:105-106); DEBUG: ||Ax-b||^2
-constexpr int kSlotRr = 1;     // r.r partial               (cg.cc:116-117, 91-92); DEBUG: ||b||^2
-constexpr int kSlotX = 2;      // DEBUG: ||x||^2            (cg.cc:151)
+constexpr int kSlotConj = 0;   // ||Ax-b||^2 partial (also: p.Ap of the gemv probe)
+constexpr int kSlotRr = 1;     // ||b||^2 partial
+constexpr int kSlotX = 2;      // ||x||^2 partial
 constexpr int kMaxRanks = 64;  // gathered[] holds kMaxRanks*kSlots doubles
 
 // Device-resident scalar block of one shard.  Nothing in the iteration loop is read back by the
 // host except `done` (polled every check_every iterations).
 struct Scalars {
     double rs[2];          // rsold / rsnew ping-pong: rs[k&1] is rsold of iteration k          (cg.cc:91,116,132)
-    double local[kSlots];  // this shard's p.Ap partial etc.: send buffer of the small all-gather
+    double local[kSlots];  // send buffer of the small scalar all-gather (verification phase)
     double dbg[4];
     int    done;           // set when sqrt(rsnew) < tol (cg.cc:120-121); later kernels exit at once
     int    k_final;        // k of the converging iteration

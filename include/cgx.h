@@ -17,7 +17,7 @@
  *
  * Sharding (code/MPI/cg.cc:59-75, 236-268): the matrix is row-block partitioned over `nranks`
  * shards exactly as partition_matrix does.  CGX_COMM_RCCL = one OS process per GPU (the MPI model),
- * RCCL AllReduce/AllGather over xGMI in place of MPI_Allreduce/MPI_Allgatherv.
+ * one RCCL AllGather per iteration over xGMI in place of 2 x MPI_Allreduce + MPI_Allgatherv.
  * CGX_COMM_LOOPBACK = `nranks` logical shards on ONE device in one process (same kernels, same
  * collective sequencing, in-process exchange) -- the CI stand-in for a multi-GPU node.
  */
@@ -48,9 +48,9 @@ typedef enum cgx_comm_mode {
     CGX_COMM_SELF = 0,        /* 1 shard, 1 device, no collectives (psize == 1)             */
     CGX_COMM_LOOPBACK = 1,    /* nranks logical shards on one device, in-process exchange   */
     CGX_COMM_RCCL = 2,        /* this process is shard `rank` of `nranks`, RCCL over xGMI   */
-    CGX_COMM_P2P = 3          /* same process model, but the two exchanges per iteration are a lean all-gather
-                                 kernel storing straight into the peers' IPC-mapped mailboxes (no RCCL at all);
-                                 needs cgx_p2p_export / cgx_p2p_import after cgx_create                       */
+    CGX_COMM_P2P = 3          /* same process model, but the one exchange per iteration stores straight into the
+                                 peers' IPC-mapped mailboxes over xGMI, folded into the update kernel (no RCCL at
+                                 all); needs cgx_p2p_export / cgx_p2p_import after cgx_create                 */
 } cgx_comm_mode;
 
 typedef struct cgx_config {
