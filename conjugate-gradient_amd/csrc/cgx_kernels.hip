@@ -35,7 +35,6 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 static constexpr double kNearZero = 1.0e-14;   // NEARZERO, code/MPI/cg.cc:8
 
-#define CGX_RLX_AGENT __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
 
 // ------------------------------------------------------------------------------------------------
 // reductions: fixed order => bitwise reproducible for a given launch shape
@@ -848,8 +847,7 @@ GemvPlan plan_gemv(int variant, int rows, int ncols)
         pl.nt = 1;
         // measured on MI355X at N=32768 (profiles/r01_k1_*): 8 rows per workgroup; two steps in flight per
         // wave once the grid is large enough to fill the chip several times over, one step below that.
-        if (rows >= 16384) { pl.R = 8; pl.U = 2; }
-        else if (rows >= 2048) { pl.R = 8; pl.U = 1; }
+        if (rows >= 2048) { pl.R = 8; pl.U = 2; }   // best or tied at 32768, 16384, 8192 and 4096 rows (tools/ab_k1.py)
         else if (rows >= 512) { pl.R = 4; pl.U = 2; }
         else { pl.R = 2; pl.U = 4; }
     } else {
