@@ -58,3 +58,16 @@ def test_p2p_config4_n32768_500_iterations_4_processes(tmp_path):
     assert v["selftest_ok"] and v["ranks_agree"], v
     assert v["k"] == 500 and not v["converged"], v
     assert v["residual_rel"] < 1e-6 and v["x_norm_rel"] < 1e-12 and v["dx"] < 1e-12, v
+
+
+def test_p2p_wait_is_bounded(tmp_path):
+    """A peer that never answers must produce CGX_ERR_P2P after the timeout, not a hang."""
+    out = tmp_path / "stall.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29707", os.path.join(ROOT, "tests", "p2p_stall_worker.py"), str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=120,
+                       env=dict(os.environ, OMP_NUM_THREADS="1", MASTER_ADDR="127.0.0.1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    v = json.load(open(out))
+    assert v["raised"] and v["status"] == 8, v
+    assert 0.3 < v["seconds"] < 2.5, v          # ~0.4 s timeout once; later exchanges return at once
