@@ -31,7 +31,7 @@ class Config(C.Structure):
     _fields_ = [
         ("struct_version", C.c_int), ("comm_mode", C.c_int), ("device", C.c_int), ("rank", C.c_int),
         ("nranks", C.c_int), ("unique_id", C.c_ubyte * UNIQUE_ID_BYTES), ("gemv_variant", C.c_int),
-        ("lda_pad", C.c_int), ("check_every", C.c_int), ("profile_gemv", C.c_int), ("use_graph", C.c_int),
+        ("lda_pad", C.c_int), ("check_every", C.c_int), ("profile_gemv", C.c_int), ("reserved0", C.c_int),
         ("p2p_mailbox_kib", C.c_int), ("p2p_timeout_ms", C.c_int), ("p2p_separate_exchange", C.c_int),
         ("reserved", C.c_int * 5),
     ]

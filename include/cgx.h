@@ -64,7 +64,7 @@ typedef struct cgx_config {
     int  lda_pad;             /* extra doubles added to the row pitch (-1 = library default)*/
     int  check_every;         /* iterations between host polls of the device `done` flag (0 = default) */
     int  profile_gemv;        /* n > 0 = bracket every n-th K1 launch with HIP events       */
-    int  use_graph;           /* 1 = replay the iteration body from a hipGraph              */
+    int  reserved0;           /* (was: hipGraph replay; not needed, the host is never the bottleneck of this loop) */
     int  p2p_mailbox_kib;     /* CGX_COMM_P2P: mailbox size in KiB (0 = 4096)               */
     int  p2p_timeout_ms;      /* CGX_COMM_P2P: bound of every in-kernel wait (0 = 5000)     */
     int  p2p_separate_exchange; /* CGX_COMM_P2P: 1 = exchange in its own kernel between K1 and K3 (default 0: folded into K3) */
