@@ -186,6 +186,18 @@ int main(int argc, char **argv)
             cfg.nranks = ngpu;
             cfg.rank = rank;
             cfg.device = same_device ? 0 : rank;
+            {
+                // every rank must own a usable GPU before any collective wire-up is attempted (a rank that cannot
+                // create a context would otherwise leave the others blocked in ncclCommInitRank)
+                cgx_config probe;
+                cgx_config_init(&probe);
+                probe.device = cfg.device;
+                cgx_ctx *pc = nullptr;
+                const int dev_ok = cgx_create(&pc, &probe) == CGX_OK;
+                if (!dev_ok) std::cerr << "cgsolver (rank " << rank << "): " << cgx_last_error(nullptr) << std::endl;
+                cgx_destroy(pc);
+                if (!all_min(dev_ok)) throw std::runtime_error("--gpus " + std::to_string(ngpu) + ": not every rank has a usable MI355X");
+            }
             bool have = false;
             if (transport != "rccl") {
                 // direct-xGMI mailboxes: create, exchange IPC handles, self-test; all ranks agree on the outcome

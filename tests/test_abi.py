@@ -80,6 +80,9 @@ def test_cli_usage_and_failure_exit_codes(pkg):
         r = subprocess.run([exe, "64", "/tmp/cgx_never_written.txt"], capture_output=True, text=True)
         assert r.returncode == 1 and "no CPU fallback" in r.stderr
         assert not os.path.exists("/tmp/cgx_never_written.txt")
+        # forked ranks: every rank reports, nobody hangs in a collective wire-up
+        r = subprocess.run([exe, "64", "/tmp/cgx_never_written.txt", "--gpus", "2"], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 1 and "not every rank has a usable MI355X" in r.stderr
 
 
 def test_product_package_never_touches_the_oracle():
