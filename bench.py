@@ -82,12 +82,26 @@ def cpu_baseline(n, iters):
     t0 = time.time()
     _, r = O.solve_lap2d(n, iters, 0.0, 1)     # tol 0: never converges, exactly `iters` loop bodies
     wall = time.time() - t0
-    return {
+    out = {
         "value": iters / r["seconds_loop"], "unit": "iterations/s", "cores": 1, "kind": "port",
         "sample": "oracle/cg_oracle.c serial CG, generate_lap2d N=%d, %d of the loop bodies timed (loop only, "
                   "%.1f s; %.1f s incl. building the 8*N^2-byte matrix)" % (n, iters, r["seconds_loop"], wall),
         "gemv_GBs": 8.0 * n * n * iters / r["seconds_loop"] / 1e9,
     }
+    # context row: all host cores of this box's share, row blocks = threads = the
+    # reference's MPI ranks; same arithmetic, bit-identical result
+    try:
+        cores = min(len(os.sched_getaffinity(0)), 16)
+    except AttributeError:
+        cores = min(os.cpu_count() or 1, 16)
+    if cores > 1:
+        O.set_threads(cores)
+        _, ra = O.solve_lap2d(n, iters, 0.0, cores)
+        O.set_threads(1)
+        out["all_cores"] = {"value": iters / ra["seconds_loop"], "unit": "iterations/s", "cores": cores, "kind": "port",
+                            "sample": "same, %d row blocks on %d threads" % (cores, cores),
+                            "gemv_GBs": 8.0 * n * n * iters / ra["seconds_loop"] / 1e9}
+    return out
 
 
 def main():

@@ -140,7 +140,13 @@ typedef struct {
     const double *A;   /* row block, ld = n */
     int start, count;
     double *r, *x, *Ap, *p, *tmp;   /* *_sub vectors, cg.cc:71-75 */
+    double part;                    /* this rank's contribution to the pending reduction */
 } rank_state;
+
+/* Row blocks may be worked on by several host threads (the reference's MPI ranks, cg.run: srun -n P): every
+ * loop over ranks below is embarrassingly parallel; the reductions over ranks stay sequential, in rank order,
+ * so the result does not depend on the thread count. */
+static int g_threads = 1;
 
 static int solve_blocks(rank_state *rk, int psize, const double *b, double *x, int n, int max_iter,
                         double tol, oracle_result *res)
@@ -169,11 +175,13 @@ static int solve_blocks(rank_state *rk, int psize, const double *b, double *x, i
     int k = 0;
     for (; k < max_iter; ++k) {                                           /* cg.cc:96 */
         double conj = 0.0;
+#pragma omp parallel for num_threads(g_threads) schedule(static) if (g_threads > 1)
         for (int q = 0; q < psize; ++q) {
             rank_state *s = &rk[q];
             oracle_gemv(s->count, n, s->A, n, p, s->Ap);                  /* cg.cc:100-102 */
-            conj += oracle_dot(s->count, s->p, s->Ap);                    /* cg.cc:105-106 */
+            s->part = oracle_dot(s->count, s->p, s->Ap);                  /* cg.cc:105 */
         }
+        for (int q = 0; q < psize; ++q) conj += rk[q].part;              /* MPI_Allreduce, cg.cc:106 */
         double safe = rsold * NEARZERO;
         double alpha = rsold / (conj > safe ? conj : safe);               /* cg.cc:107 */
         rsnew = 0.0;
@@ -281,6 +289,7 @@ int oracle_solve_lap2d(int n, int max_iter, double tol, int psize, double *x, or
     oracle_partition(n, psize, start, num);
     oracle_init_source_term(n, 1. / n, b);                                /* cg_main.cc:45-46 */
     int rc = 0;
+#pragma omp parallel for num_threads(g_threads) schedule(static) if (g_threads > 1)
     for (int q = 0; q < psize; ++q) {
         blocks[q] = (double *)malloc((size_t)(num[q] > 0 ? num[q] : 1) * (size_t)n * sizeof(double));
         if (!blocks[q]) { rc = -1; continue; }
@@ -332,6 +341,8 @@ int oracle_read_mtx_dense(const char *path, int *m_out, int *n_out, int *nz_out,
     *m_out = m; *n_out = n; *nz_out = nz; *sym_out = is_sym; *A_out = A;
     return 0;
 }
+
+void oracle_set_threads(int nthreads) { g_threads = nthreads > 0 ? nthreads : 1; }
 
 /* ---- bench.py cpu_baseline leg: time `reps` GEMV passes over `nrows` generated rows -------- */
 double oracle_time_gemv_rows(int n, int nrows, int reps)

@@ -50,6 +50,10 @@ void oracle_init_source_term(int n, double h, double *b);
 int oracle_solve(const double *A, const double *b, double *x, int n, int max_iter,
                  double tol, int psize, oracle_result *res);
 
+/* Host threads that work on the row blocks of the psize logical ranks (default 1 = the serial path).  Results do
+ * not depend on it: reductions over ranks are always done sequentially in rank order. */
+void oracle_set_threads(int nthreads);
+
 /* Same recurrence, but A is never materialised as one block by the caller: the oracle
  * allocates psize row blocks itself with oracle_generate_lap2d_rows (used for large N). */
 int oracle_solve_lap2d(int n, int max_iter, double tol, int psize, double *x, oracle_result *res);

@@ -68,6 +68,8 @@ def lib():
         L.oracle_axpy.restype = None
         L.oracle_read_mtx_dense.argtypes = [C.c_char_p, ip, ip, ip, ip, C.POINTER(dp)]
         L.oracle_read_mtx_dense.restype = C.c_int
+        L.oracle_set_threads.argtypes = [C.c_int]
+        L.oracle_set_threads.restype = None
         L.oracle_time_gemv_rows.argtypes = [C.c_int, C.c_int, C.c_int]
         L.oracle_time_gemv_rows.restype = C.c_double
         _lib = L
@@ -126,6 +128,11 @@ def solve(A, b, x0=None, max_iter=None, tol=1e-10, psize=1):
     if rc:
         raise RuntimeError("oracle_solve failed: %d" % rc)
     return x, res.as_dict()
+
+
+def set_threads(nthreads):
+    """Host threads working on the logical ranks' row blocks (results do not depend on it)."""
+    lib().oracle_set_threads(int(nthreads))
 
 
 def solve_lap2d(n, max_iter=None, tol=1e-10, psize=1):
