@@ -7,9 +7,9 @@
  *
  * Each function cites the reference file:line (relative to /root/reference) it restates.
  *
- * Pinning status: the reference has no tests and no golden vectors, and its MPI sources need
- * <cblas.h> + a CBLAS library that this image does not ship, so oracle/_ref is unbuildable here
- * under the "no stand-in headers" rule.  The oracle is pinned against the reference outputs the
+ * Pinning status: the reference has no tests and no golden vectors, and its solver (cg.cc) needs
+ * <cblas.h> + a CBLAS library that this image does not ship, so it cannot be built into oracle/_ref
+ * under the "no stand-in headers" rule (only its Matrix-Market reader can: `make -C oracle ref`).  The oracle is pinned against the reference outputs the
  * survey stage recorded from the compiled reference (committed as
  * tests/golden/reference_probe.json).  Those values are not regenerable from this repo.
  *

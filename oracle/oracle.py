@@ -160,5 +160,33 @@ def read_mtx_dense(path):
     return A, nz.value, bool(sym.value)
 
 
+_REF_LIB_PATH = os.path.join(_HERE, "_ref", "libref_matrix.so")
+_ref = None
+
+
+def ref_available():
+    """True if oracle/_ref/libref_matrix.so (the REFERENCE's own Matrix-Market reader, built from its sources by
+    `make -C oracle ref` where /root/reference exists) is present.  The built file travels to the GPU box."""
+    return os.path.exists(_REF_LIB_PATH)
+
+
+def ref_read_mtx_dense(path):
+    """Matrix::read of the reference itself (code/MPI/matrix.cc:6-22).  Valid files only: it exit()s on errors."""
+    global _ref
+    if _ref is None:
+        _ref = C.CDLL(_REF_LIB_PATH)
+        _ref.ref_matrix_read.argtypes = [C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.POINTER(C.c_double))]
+        _ref.ref_matrix_read.restype = C.c_int
+    m = C.c_int()
+    n = C.c_int()
+    ptr = C.POINTER(C.c_double)()
+    rc = _ref.ref_matrix_read(os.fsencode(path), C.byref(m), C.byref(n), C.byref(ptr))
+    if rc:
+        raise RuntimeError("ref_matrix_read failed: %d" % rc)
+    A = np.ctypeslib.as_array(ptr, shape=(m.value, n.value)).copy()
+    C.CDLL(None).free(ptr)
+    return A
+
+
 def time_gemv_rows(n, nrows, reps):
     return lib().oracle_time_gemv_rows(n, nrows, reps)

@@ -232,6 +232,28 @@ def test_mtx_reader_matches_oracle_dense(gpu_pkg, oracle, mtx_path):
         assert np.array_equal(np.vstack(blocks), A)
 
 
+def test_mtx_reader_matches_the_reference_reader(gpu_pkg, oracle, mtx_path, tmp_path):
+    """libcgx's reader against the REFERENCE's own Matrix::read (oracle/_ref, prebuilt where the reference exists)."""
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref/libref_matrix.so not present")
+    cases = {"fixture": mtx_path}
+    texts = {
+        "general_dups.mtx": "%%MatrixMarket matrix coordinate real general\n% comment\n4 4 7\n1 1 2.5\n2 2 1\n3 3 4e0\n4 4 -3\n1 3 -1\n1 3 -7\n4 1 0.125\n",
+        "symmetric.mtx": "%%MatrixMarket matrix coordinate real symmetric\n5 5 6\n1 1 4\n2 1 -1\n3 3 4\n5 2 7.5\n5 5 1\n4 4 2\n",
+    }
+    for name, text in texts.items():
+        f = tmp_path / name
+        f.write_text(text)
+        cases[name] = str(f)
+    for name, path in cases.items():
+        A_ref = oracle.ref_read_mtx_dense(path)
+        for mode, p in ((gpu_pkg.COMM_SELF, 1), (gpu_pkg.COMM_LOOPBACK, 2)):
+            with gpu_pkg.CGSolver(comm_mode=mode, nranks=p) as s:
+                s.read_matrix(path)
+                A = np.vstack([s.probe_matrix_rows(i)[0] for i in range(p)])
+            assert np.array_equal(A, A_ref), (name, p)
+
+
 def test_mtx_general_duplicates_and_errors(gpu_pkg, tmp_path):
     f = tmp_path / "g.mtx"
     f.write_text("%%MatrixMarket MATRIX Coordinate Real General\n% c\n%c2\n3 3 5\n1 1 2.5\n2 2 1\n3 3 4e0\n1 3 -1\n1 3 -7\n")

@@ -173,3 +173,23 @@ def test_mtx_solve_matches_reference(oracle, mtx_path, reference_probe):
     # against the same golden row; here only sanity of the early iterations.
     assert r["residual_prev"] > 1.0 and np.isfinite(r["x_norm"])
     assert row["k"] == 488
+
+
+# ---- oracle/_ref: the reference's own reader, compiled from its sources ------------------------------------
+MTX_CASES = {
+    "general_dups.mtx": "%%MatrixMarket matrix coordinate real general\n% comment\n%another\n4 4 7\n1 1 2.5\n2 2 1\n3 3 4e0\n4 4 -3\n1 3 -1\n1 3 -7\n4 1 0.125\n",
+    "symmetric.mtx": "%%MatrixMarket matrix coordinate real symmetric\n5 5 6\n1 1 4\n2 1 -1\n3 3 4\n5 2 7.5\n5 5 1\n4 4 2\n",
+    "integer_caps.mtx": "%%MatrixMarket MATRIX COORDINATE INTEGER GENERAL\n3 3 3\n1 1 1\n2 2 2\n3 3 3\n",
+}
+
+
+def test_oracle_reader_matches_the_reference_reader(oracle, mtx_path, tmp_path):
+    if not oracle.ref_available():
+        pytest.skip("oracle/_ref not built (needs /root/reference: `make -C oracle ref`)")
+    A_ref = oracle.ref_read_mtx_dense(mtx_path)
+    A, _, _ = oracle.read_mtx_dense(mtx_path)
+    assert np.array_equal(A, A_ref)
+    for name, text in MTX_CASES.items():
+        f = tmp_path / name
+        f.write_text(text)
+        assert np.array_equal(oracle.read_mtx_dense(str(f))[0], oracle.ref_read_mtx_dense(str(f))), name
