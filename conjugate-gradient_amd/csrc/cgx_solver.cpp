@@ -948,6 +948,7 @@ cgx_status cgx_solve_steps(cgx_ctx *ctx, int nsteps, int *done_out)
     ctx->ev_used = 0;
     ctx->gemv_ms_sum = ctx->gemv_ms_min = 0;
     ctx->gemv_launches = 0;
+    ctx->gemv_seq = 0;   // the first K1 of every steps call is always one of the sampled launches
     const int every = ctx->cfg.check_every;
     int slot = 0;
     bool pending[2] = {false, false};
