@@ -193,6 +193,28 @@ def test_break_semantics_and_no_further_updates(gpu_pkg):
     assert rs[0]["residual_prev"] == rs[2]["residual_prev"] and rs[0]["residual_last"] == rs[2]["residual_last"]
 
 
+def test_context_is_reusable(gpu_pkg, oracle):
+    """Two solves on one context (buffers are kept), then a new right-hand side and a new size on the same context."""
+    n = 1024
+    with make(gpu_pkg, n, max_iter=120) as s:
+        x1 = np.zeros(n); r1 = s.solve(x1)
+        x2 = np.zeros(n); r2 = s.solve(x2)
+        assert np.array_equal(x1, x2) and r1["residual_prev"] == r2["residual_prev"]
+        s.generate_lap2d_matrix(n)                      # same geometry: allocation is reused
+        s.set_max_iter(120)
+        b = np.cos(np.arange(n))
+        s.set_source_term(b)
+        x3 = np.zeros(n); r3 = s.solve(x3)
+        xo, ro = oracle.solve(oracle.generate_lap2d(n), b, None, 120, 1e-10, 1)
+        assert np.linalg.norm(x3 - xo) / np.linalg.norm(xo) < 1e-12 and rel(r3["residual_prev"], ro["residual_prev"]) < 1e-6
+        s.generate_lap2d_matrix(777)                    # new geometry on the same context
+        s.set_max_iter(50)
+        s.init_source_term(1.0 / 777)
+        x4 = np.zeros(777); r4 = s.solve(x4)
+    xo, ro = oracle.solve_lap2d(777, 50, 1e-10, 1)
+    assert np.linalg.norm(x4 - xo) / np.linalg.norm(xo) < 1e-12 and r4["iterations"] == 50
+
+
 def test_initial_guess_is_used(gpu_pkg, oracle):
     n = 512
     A = oracle.generate_lap2d(n)
