@@ -352,6 +352,29 @@ def test_config5_weak_scaling_sizes(gpu_pkg, reference_probe, n, p):
     _check_against_reference(x, r, row)
 
 
+def test_beyond_int_indexing_n65536(gpu_pkg):
+    """N=65536: N*N = 2^32 elements, past the reference's `int` index (matrix.hh:17 overflows above N=46340).
+    32 GiB of A on one GPU; no CPU oracle at this size, so size-independent properties: exact row sums, and the
+    same solution from 1 and from 4 row blocks."""
+    n = 65536
+    inc = int(np.floor(np.sqrt(n)))
+    xs = []
+    for mode, p in ((gpu_pkg.COMM_SELF, 1), (gpu_pkg.COMM_LOOPBACK, 4)):
+        with gpu_pkg.CGSolver(comm_mode=mode, nranks=p) as s:
+            s.generate_lap2d_matrix(n)
+            if p == 1:
+                ones, _ = s.probe_gemv(np.ones(n))
+                assert ones[0] == 2.0 and ones[1] == 1.0 and ones[inc + 1] == 0.0 and ones[n // 2] == 0.0 and ones[n - 1] == 2.0
+            s.set_max_iter(25)
+            s.init_source_term(1.0 / n)
+            x = np.zeros(n)
+            r = s.solve(x)
+            assert r["iterations"] == 25 and np.isfinite(r["residual_prev"])
+            xs.append((x, r))
+    assert np.linalg.norm(xs[0][0] - xs[1][0]) / np.linalg.norm(xs[0][0]) < 1e-13
+    assert rel(xs[0][1]["residual_prev"], xs[1][1]["residual_prev"]) < 1e-10
+
+
 # ---- command line -------------------------------------------------------------------------------------------------
 def test_cgsolver_cli_both_forms(gpu_pkg, mtx_path, tmp_path):
     exe = os.path.join(ROOT, "conjugate-gradient_amd", "cgsolver")
