@@ -682,7 +682,7 @@ __global__ __launch_bounds__(256) void k_mailbox_allgather(MailboxView mv, int c
             mv.base[mv.rank] + ((long)chan * kMaxRanks + peer) * kP2pFlagStride);
         const long long t0 = wall_clock64();
         int ok = 1;
-        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {   // relaxed polls, ONE acquire after
             __builtin_amdgcn_s_sleep(8);
             if (wall_clock64() - t0 > timeout_ticks) {   // every spin is bounded: give up, tell the host
                 ok = 0;
@@ -773,7 +773,9 @@ __global__ __launch_bounds__(256) void k_update_xr_p2p(int n, int rows, int row0
         const unsigned long long *flag = reinterpret_cast<const unsigned long long *>(
             mv.base[me] + ((long)chan * kMaxRanks + tid) * kP2pFlagStride);
         const long long t0 = wall_clock64();
-        while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+        // relaxed polls (an acquire per poll would invalidate caches every time round); everything read after the
+        // barrier below is read with system-scope loads, which are served from memory, never from a stale line
+        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
             __builtin_amdgcn_s_sleep(4);
             if (wall_clock64() - t0 > timeout_ticks) {
                 ok = 0;
@@ -783,7 +785,6 @@ __global__ __launch_bounds__(256) void k_update_xr_p2p(int n, int rows, int row0
         }
     }
     if (!__syncthreads_and(ok)) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");   // system scope
     const unsigned long long *box = reinterpret_cast<const unsigned long long *>(mv.base[me] + mv.data_off[chan]);
     const long slot_w = slot / 8;
     if (tid < P)

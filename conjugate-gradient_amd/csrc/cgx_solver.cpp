@@ -436,7 +436,7 @@ cgx_status enqueue_iteration(cgx_ctx *ctx, int k)
     hipStream_t st = ctx->stream;
     // tail of iteration k-1 (cg.cc:117-132) + GEMV and p.Ap partials of iteration k (cg.cc:100-105)
     for (auto &s : ctx->shards) CGX_TRY(run_gemv_fused(ctx, s, k));
-    if (ctx->cfg.comm_mode == CGX_COMM_P2P && ctx->nranks > 1 && !ctx->cfg.p2p_separate_exchange) {
+    if (ctx->cfg.comm_mode == CGX_COMM_P2P && !ctx->cfg.p2p_separate_exchange) {
         // direct peer exchange folded into K3: the iteration is two kernels, no collective launch at all
         Shard &s = ctx->shards[0];
         if (!ctx->p2p_ready) return fail(ctx, CGX_ERR_P2P, "cgx_p2p_import has not been called");
