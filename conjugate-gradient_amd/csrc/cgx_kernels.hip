@@ -482,10 +482,14 @@ __global__ __launch_bounds__(256) void k_update_xr(int n, int rows, int row0, co
     // p.Ap = sum of every K1 workgroup partial of every rank (cblas_ddot + MPI_Allreduce, cg.cc:105-106), folded
     // in one fixed order by every workgroup of every rank: bit-identical everywhere.
     double cs = 0.0;
-    const int total = apv.nranks * tail_count;
-    for (int t = threadIdx.x; t < total; t += 256) {
-        const int q = t / tail_count, j = t - q * tail_count;
-        cs += apv.base[(long)q * apv.S + apv.Sr + tail_off + j];
+    for (int q = 0; q < apv.nranks; ++q) {
+        const double *tail = apv.base + (long)q * apv.S + apv.Sr + tail_off;
+        int j = threadIdx.x;
+        for (; j + 3 * 256 < tail_count; j += 4 * 256) {   // four independent loads in flight
+            const double a0 = tail[j], a1 = tail[j + 256], a2 = tail[j + 512], a3 = tail[j + 768];
+            cs += (a0 + a1) + (a2 + a3);
+        }
+        for (; j < tail_count; j += 256) cs += tail[j];
     }
     if (done) return;   // converged earlier (uniform over the grid): nothing is written
     const double conj = block_sum<4>(cs, lds);
@@ -747,7 +751,15 @@ __global__ __launch_bounds__(256) void k_update_xr_p2p(int n, int rows, int row0
     if (own) { p_i = p_new[i]; x_i = x[li]; }
     const double *mine = apv.base + (long)me * apv.S;   // my segment: [Ap slice | npart partials]
     double v = 0.0;
-    for (int t = tid; t < npart; t += 256) v += mine[apv.Sr + t];
+    {
+        const double *tail = mine + apv.Sr;
+        int j = tid;
+        for (; j + 3 * 256 < npart; j += 4 * 256) {   // four independent loads in flight
+            const double a0 = tail[j], a1 = tail[j + 256], a2 = tail[j + 512], a3 = tail[j + 768];
+            v += (a0 + a1) + (a2 + a3);
+        }
+        for (; j < npart; j += 256) v += tail[j];
+    }
     // `done` is identical on every rank (r.r is bit-identical), so either all ranks exchange or none does
     if (__syncthreads_or(done | had_err)) return;
     const double my_sum = block_sum<4>(v, lds);         // local half of MPI_Allreduce(p.Ap), cg.cc:105-106
