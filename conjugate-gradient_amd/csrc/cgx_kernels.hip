@@ -76,6 +76,7 @@ __device__ __forceinline__ d2 load_a(const double *ptr)
 // round-up magic number (div_magic, div_shift) for n_loc (seg_finalize), exact for 0 <= c < 2^31.
 __device__ __forceinline__ int seg_owner(const SegView &sv, int c)
 {
+    if (sv.n_loc <= 0) return sv.nranks - 1;   // N < P: floor(N/P) = 0 rows everywhere but on the last rank (cg.cc:255-266)
     const int t = (sv.div_shift == 32) ? c : (int)(__umulhi((unsigned)c, sv.div_magic) >> sv.div_shift);
     return t < sv.nranks - 1 ? t : sv.nranks - 1;
 }
@@ -836,8 +837,9 @@ void seg_finalize(SegView *sv)
     sv->seg_gap = sv->S - sv->n_loc;
     // Round-up magic for dividends c < 2^31 (Granlund-Montgomery): s = ceil(log2 d), m = floor(2^(31+s)/d) + 1
     // fits 32 bits and floor(c/d) == (c*m) >> (31+s) == umulhi(c,m) >> (s-1) exactly.  d == 1 is flagged by
-    // div_shift == 32 (quotient = c); n_loc == 0 (N < P: every column belongs to the last rank) uses d = 2^31 - 1.
-    const unsigned d = sv->n_loc > 0 ? (unsigned)sv->n_loc : 0x7fffffffu;
+    // div_shift == 32 (quotient = c); n_loc == 0 (N < P: every column belongs to the last rank) is handled by
+    // seg_owner itself and needs no magic.
+    const unsigned d = sv->n_loc > 0 ? (unsigned)sv->n_loc : 1u;
     if (d == 1) {
         sv->div_magic = 0;
         sv->div_shift = 32;

@@ -162,6 +162,19 @@ def test_fixed_iteration_solve_matches_oracle(gpu_pkg, oracle, n, max_iter, mode
     assert rel(r["rel_residual"], ro["rel_residual"]) < tol
 
 
+@pytest.mark.parametrize("n,max_iter,p,variant", [(3, 2, 4, 0), (5, 3, 8, 0), (7, 4, 7, 0), (9, 5, 4, 20441), (2, 1, 3, 0)])
+def test_fewer_rows_than_ranks(gpu_pkg, oracle, n, max_iter, p, variant):
+    """N < P or N ~ P: shards without rows (floor(N/P) = 0, cg.cc:255) still take part in every exchange.  tol = 0
+    on both sides so that the comparison does not depend on which side's rounding converges first."""
+    with make(gpu_pkg, n, gpu_pkg.COMM_LOOPBACK, p, variant, max_iter, tol=0.0) as s:
+        x = np.zeros(n)
+        r = s.solve(x)
+    xo, ro = oracle.solve_lap2d(n, max_iter, 0.0, p)
+    assert r["iterations"] == ro["iterations"] == max_iter
+    assert np.linalg.norm(x - xo) <= 1e-12 * np.linalg.norm(xo)
+    assert rel(r["x_norm"], ro["x_norm"]) < 1e-12
+
+
 @pytest.mark.parametrize("n,mode,p", [(1024, None, 1), (1024, 1, 4), (1000, 1, 3), (2048, None, 1), (4096, None, 1)])
 def test_converged_solve(gpu_pkg, oracle, reference_probe, n, mode, p):
     with make(gpu_pkg, n, mode, p) as s:
