@@ -240,6 +240,33 @@ def test_initial_guess_is_used(gpu_pkg, oracle):
     assert np.linalg.norm(x - xo) / np.linalg.norm(xo) < 1e-12 and rel(r["residual_prev"], ro["residual_prev"]) < 1e-6
 
 
+def test_initial_guess_and_host_pitch_with_row_blocks(gpu_pkg, oracle):
+    """Non-zero x0 with 3 row blocks, and a host matrix handed over with a leading dimension larger than n."""
+    import ctypes as C
+    n, lda = 300, 320
+    rng = np.random.default_rng(5)
+    M = rng.standard_normal((n, n))
+    A = M @ M.T + n * np.eye(n)                                   # SPD, dense
+    Apad = np.zeros((n, lda))
+    Apad[:, :n] = A
+    Apad[:, n:] = 7.0                                             # must be ignored
+    b = rng.standard_normal(n)
+    x0 = rng.standard_normal(n)
+    with gpu_pkg.CGSolver(comm_mode=gpu_pkg.COMM_LOOPBACK, nranks=3) as s:
+        L = gpu_pkg.cgx.lib()
+        st = L.cgx_set_matrix_dense(s._h, Apad.ctypes.data_as(C.POINTER(C.c_double)), lda, n)
+        assert st == 0
+        back = np.vstack([s.probe_matrix_rows(i)[0] for i in range(3)])
+        assert np.array_equal(back, A)
+        s.set_source_term(b)
+        s.set_max_iter(25)
+        x = x0.copy()
+        r = s.solve(x)
+    xo, ro = oracle.solve(A, b, x0, 25, 1e-10, 3)
+    assert r["iterations"] == ro["iterations"]
+    assert np.linalg.norm(x - xo) / np.linalg.norm(xo) < 1e-12
+
+
 def test_max_iter_zero_and_exact_solution(gpu_pkg):
     n = 256
     with make(gpu_pkg, n, max_iter=0) as s:
