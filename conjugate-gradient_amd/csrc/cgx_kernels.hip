@@ -645,7 +645,9 @@ __global__ __launch_bounds__(256) void k_mailbox_allgather(MailboxView mv, int c
 {
     const int peer = blockIdx.x;
     const int tid = threadIdx.x;
-    if (*reinterpret_cast<volatile int *>(err)) return;   // an earlier wait expired: do not wait again, let the host see it
+    // an earlier wait expired: do not wait again, let the host see it.  Decided per workgroup (another workgroup may
+    // raise the word while this one starts), so that no thread is left alone at a barrier.
+    if (__syncthreads_or(*reinterpret_cast<volatile int *>(err))) return;
     __shared__ double lds[4];
     double tail_sum = 0.0;
     if (tail_n > 0) {
