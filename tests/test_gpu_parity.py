@@ -370,12 +370,13 @@ def test_config2_n10000_converges_like_reference(gpu_pkg, reference_probe):
     assert rel(r["x_norm"], row["x_norm"]) < 1e-6 and r["rel_residual"] <= 3e-11
 
 
-@pytest.mark.parametrize("mode,p", [(None, 1), (1, 8)])
-def test_config3_n32768_500_iterations(gpu_pkg, reference_probe, mode, p):
-    """The roofline point and (as 8 logical row blocks on one GPU) the strong-scaling partition."""
+@pytest.mark.parametrize("mode,p,variant", [(None, 1, 0), (1, 2, 0), (1, 4, 0), (1, 8, 0), (None, 1, 20441), (1, 8, 20241)])
+def test_config3_n32768_500_iterations(gpu_pkg, reference_probe, mode, p, variant):
+    """The roofline point and (as 2/4/8 logical row blocks on one GPU) the strong-scaling partitions, with the default
+    K1 and with the LDS-staged variant."""
     row = [q for q in reference_probe["generated_large"] if q["n"] == 32768][0]
     n = 32768
-    with make(gpu_pkg, n, mode, p, max_iter=500) as s:
+    with make(gpu_pkg, n, mode, p, variant, max_iter=500) as s:
         x = np.zeros(n)
         r = s.solve(x)
     _check_against_reference(x, r, row)
