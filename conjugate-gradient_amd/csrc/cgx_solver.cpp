@@ -192,6 +192,13 @@ void free_problem(cgx_ctx *ctx)
     ctx->in_solve = false;
 }
 
+// Mailbox bytes before the segment channel: flag words, channel 0 (16-B slots) and channel 2 (kSlots doubles).
+long p2p_fixed_prefix(int nranks)
+{
+    return (long)cgx::kP2pChannels * cgx::kMaxRanks * cgx::kP2pFlagStride + 2L * nranks * 16 +
+           2L * nranks * (long)cgx::kSlots * 8;
+}
+
 long default_lda(const cgx_ctx *ctx, int n)
 {
     long lda = ((long)n + 15) / 16 * 16;   // every row starts on a 128-B line
@@ -245,14 +252,19 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
         ctx->npart = std::max(ctx->npart, cgx::plan_gemv(variant, ctx->num_rows[q], (int)ctx->lda).grid);
     if (ctx->cfg.comm_mode == CGX_COMM_P2P) {
         // mailbox layout of this problem: flags, then per channel [2 parities][nranks] slots
-        const long flags_bytes = (long)cgx::kP2pChannels * cgx::kMaxRanks * cgx::kP2pFlagStride;
+        // The small fixed-size channels come first, so that their place never depends on the problem; the
+        // segment channel (1), whose slot size does, comes last.  A re-layout for a new problem size is then
+        // safe without a launcher barrier: the last exchange of a solve is on channel 2, and a rank can finish
+        // it only after every peer has pushed its channel-2 data, i.e. after every peer is done with channel 1.
         const long slot[cgx::kP2pChannels] = {16, ((long)(ctx->seg_Sr + 1) * 8 + 15) / 16 * 16, (long)cgx::kSlots * 8};
-        long off = flags_bytes;
-        for (int c = 0; c < cgx::kP2pChannels; ++c) {
-            ctx->mv.data_off[c] = off;
-            ctx->mv.slot_bytes[c] = slot[c];
-            off += 2L * ctx->nranks * slot[c];
-        }
+        long off = p2p_fixed_prefix(ctx->nranks);
+        ctx->mv.data_off[0] = (long)cgx::kP2pChannels * cgx::kMaxRanks * cgx::kP2pFlagStride;
+        ctx->mv.slot_bytes[0] = slot[0];
+        ctx->mv.data_off[2] = ctx->mv.data_off[0] + 2L * ctx->nranks * slot[0];
+        ctx->mv.slot_bytes[2] = slot[2];
+        ctx->mv.data_off[1] = off;
+        ctx->mv.slot_bytes[1] = slot[1];
+        off += 2L * ctx->nranks * slot[1];
         if ((size_t)off > ctx->mailbox_bytes)
             return fail(ctx, CGX_ERR_P2P, "mailbox too small for this problem: need " + std::to_string(off) +
                                               " bytes (raise cgx_config.p2p_mailbox_kib)");
@@ -668,7 +680,7 @@ cgx_status cgx_p2p_selftest(cgx_ctx *ctx, int rounds, int *ok)
     const int P = ctx->nranks, me = ctx->cfg.rank;
     const int count = 1024;   // doubles per rank: 8 KiB, the size class of the real exchanges
     cgx::MailboxView saved = ctx->mv;
-    ctx->mv.data_off[1] = (long)cgx::kP2pChannels * cgx::kMaxRanks * cgx::kP2pFlagStride;
+    ctx->mv.data_off[1] = p2p_fixed_prefix(P);
     ctx->mv.slot_bytes[1] = (long)count * 8;
     if ((size_t)(ctx->mv.data_off[1] + 2L * P * count * 8) > ctx->mailbox_bytes) {
         ctx->mv = saved;

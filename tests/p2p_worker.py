@@ -65,6 +65,22 @@ def main():
                    "dx": float(np.linalg.norm(x - xo) / np.linalg.norm(xo)),
                    "residual_rel": float(abs(res["residual_prev"] - ro["residual_prev"]) / ro["residual_prev"]),
                    "seconds_solve": res["seconds_solve"]}, open(out_path, "w"))
+    # Second problem of a DIFFERENT size on the same contexts, with no launcher barrier in between: the mailbox is
+    # re-laid-out while peers may still be finishing the previous solve (safe by construction).
+    if 64 <= n <= 4096:
+        n2 = n // 2 + 3
+        s.generate_lap2d_matrix(n2)
+        s.set_max_iter(40)
+        s.init_source_term(1.0 / n2)
+        x2 = np.zeros(n2)
+        res2 = s.solve(x2)
+        if rank == 0:
+            O = g.load_oracle()
+            xo2, ro2 = O.solve_lap2d(n2, 40, 1e-10, world)
+            v = json.load(open(out_path))
+            v["second_dx"] = float(np.linalg.norm(x2 - xo2) / np.linalg.norm(xo2))
+            v["second_k"] = [res2["iterations"], ro2["iterations"]]
+            json.dump(v, open(out_path, "w"))
     s.close()
     dist.barrier()
     dist.destroy_process_group()
