@@ -855,16 +855,19 @@ void seg_finalize(SegView *sv)
 
 GemvPlan plan_gemv(int variant, int rows, int ncols)
 {
-    (void)ncols;
     GemvPlan pl{};
     pl.waves = 4;
     if (variant <= 0) {
-        // default: column-split, as many rows per workgroup as still leaves >= 4 workgroups per CU
+        // default: column-split; the shape comes from measurements on MI355X (profiles/r01_k1_*, tools/ab_k1.py,
+        // tools/small_n.py, tools/shard_plain.py):
+        //  - blocks that stream from HBM (more than the 256 MiB of Infinity Cache): 8 rows per workgroup, two
+        //    steps in flight per wave -- best or tied from 6144^2 up to 32768^2 and on 4096 x 32768 shards;
+        //  - blocks that fit in the Infinity Cache (N <= ~5700 on one GPU): the launch is latency-bound, not
+        //    bandwidth-bound, and twice as many 4-row workgroups are 8-11 % faster (N = 2048 ... 5120).
         pl.variant = 1;
         pl.nt = 1;
-        // measured on MI355X at N=32768 (profiles/r01_k1_*): 8 rows per workgroup; two steps in flight per
-        // wave once the grid is large enough to fill the chip several times over, one step below that.
-        if (rows >= 2048) { pl.R = 8; pl.U = 2; }   // best or tied at 32768, 16384, 8192 and 4096 rows (tools/ab_k1.py)
+        const double block_bytes = 8.0 * (double)rows * (double)ncols;
+        if (rows >= 2048 && block_bytes > 256.0 * 1024 * 1024) { pl.R = 8; pl.U = 2; }
         else if (rows >= 512) { pl.R = 4; pl.U = 2; }
         else { pl.R = 2; pl.U = 4; }
     } else {

@@ -4,8 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 pkg = g.load_package()
 n = 32768
-for P in (8, 4, 1):
-    for v in (10821, 10811, 10441, 11611):
+for P in (8, 4, 2):
+    for v in (10821, 10421, 10441, 10811):
         with pkg.CGSolver(comm_mode=pkg.COMM_LOOPBACK if P > 1 else pkg.COMM_SELF, nranks=P, gemv_variant=v) as s:
             s.generate_lap2d_matrix(n)
             for _ in range(3): s.probe_time_gemv(20)
