@@ -106,6 +106,11 @@ def cpu_baseline(n, iters):
 
 def main():
     args = parse_args()
+    # stdout carries the ONE JSON line and nothing else: whatever the libraries print on fd 1 while the run is
+    # going (RCCL's version banner, for one) is sent to stderr instead.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -167,38 +172,73 @@ def main():
             dist.barrier()
 
     def make_solver(transport):
-        """transport: 'self' | 'rccl' | 'p2p'.  Returns a ready solver or None (same answer on every rank)."""
+        """transport: 'self' | 'rccl' | 'p2p' | 'p2p-sep'.  Returns a ready solver or None (same answer on every rank).
+        The wire-up is cut into stages; after each one all ranks agree (all_ok) whether to go on, so that a failure on
+        one rank can never leave the others inside a different torch.distributed call."""
         common = dict(nranks=world, rank=rank, device=local_rank, gemv_variant=args.variant, lda_pad=args.lda_pad,
                       profile_gemv=profile_every)
-        s = None
-        ok = True
-        try:
-            if transport == "self":
-                s = pkg.CGSolver(comm_mode=pkg.COMM_SELF, **common)
-            elif transport == "rccl":
-                # replaces mpirun's wire-up (MPI_Init, cg_main.cc:15-20): every rank gets rank 0's RCCL id
-                uid = broadcast_bytes(dist, pkg.comm_unique_id() if rank == 0 else None, pkg.cgx.UNIQUE_ID_BYTES, ctl)
-                s = pkg.CGSolver(comm_mode=pkg.COMM_RCCL, unique_id=uid, **common)
-            else:
-                s = pkg.CGSolver(comm_mode=pkg.COMM_P2P, p2p_separate_exchange=(transport == "p2p-sep"), **common)
-                mine = torch.tensor(list(s.p2p_export()), dtype=torch.uint8, device=ctl)
-                allh = [torch.zeros_like(mine) for _ in range(world)]
-                dist.all_gather(allh, mine)          # every rank's mailbox handle to every rank
-                s.p2p_import(b"".join(bytes(t.cpu().tolist()) for t in allh))
-                dist.barrier()
-                ok = s.p2p_selftest(32)              # pattern all-gathers, verified, every wait bounded
-            # The problem is set up ONCE per solver: re-allocating the 8 GiB matrix after a free can land on
-            # fragmented memory and cost ~3 % of K1 (measured), so calibration and timed run share one allocation.
-            s.generate_lap2d_matrix(n)
-            s.init_source_term(1.0 / n)
-        except Exception as e:                       # noqa: BLE001 -- any failure means "do not use this transport"
-            print("bench.py rank %d: transport %s unavailable: %s" % (rank, transport, e), file=sys.stderr, flush=True)
-            ok = False
-        if not all_ok(ok):
-            if s is not None:
-                s.close()
+        box = {"s": None, "uid": None, "handle": None, "all_handles": None}
+
+        def stage(what, fn):
+            ok = True
+            try:
+                ok = fn() is not False
+            except Exception as e:                   # noqa: BLE001 -- any failure means "do not use this transport"
+                print("bench.py rank %d: transport %s unavailable (%s): %s" % (rank, transport, what, e),
+                      file=sys.stderr, flush=True)
+                ok = False
+            return all_ok(ok)
+
+        def give_up():
+            if box["s"] is not None:
+                box["s"].close()
             return None
-        return s
+
+        if transport == "self":
+            def create():
+                box["s"] = pkg.CGSolver(comm_mode=pkg.COMM_SELF, **common)
+            if not stage("create", create):
+                return give_up()
+        elif transport == "rccl":
+            # replaces mpirun's wire-up (MPI_Init, cg_main.cc:15-20): every rank gets rank 0's RCCL id
+            def make_id():
+                box["uid"] = pkg.comm_unique_id() if rank == 0 else None
+            if not stage("unique id", make_id):
+                return give_up()
+            uid = broadcast_bytes(dist, box["uid"], pkg.cgx.UNIQUE_ID_BYTES, ctl)
+
+            def create():
+                box["s"] = pkg.CGSolver(comm_mode=pkg.COMM_RCCL, unique_id=uid, **common)
+            if not stage("ncclCommInitRank", create):
+                return give_up()
+        else:
+            def create():
+                box["s"] = pkg.CGSolver(comm_mode=pkg.COMM_P2P, p2p_separate_exchange=(transport == "p2p-sep"), **common)
+                box["handle"] = box["s"].p2p_export()
+            if not stage("mailbox allocation", create):
+                return give_up()
+            mine = torch.tensor(list(box["handle"]), dtype=torch.uint8, device=ctl)
+            allh = [torch.zeros_like(mine) for _ in range(world)]
+            dist.all_gather(allh, mine)              # every rank's mailbox handle to every rank
+
+            def attach():
+                box["s"].p2p_import(b"".join(bytes(t.cpu().tolist()) for t in allh))
+            if not stage("opening the peers' mailboxes", attach):   # also the barrier: every rank has attached
+                return give_up()
+
+            def selftest():
+                return bool(box["s"].p2p_selftest(32))   # pattern all-gathers, verified, every wait bounded
+            if not stage("self-test", selftest):
+                return give_up()
+
+        # The problem is set up ONCE per solver: re-allocating the 8 GiB matrix after a free can land on
+        # fragmented memory and cost ~3 % of K1 (measured), so calibration and timed run share one allocation.
+        def problem():
+            box["s"].generate_lap2d_matrix(n)
+            box["s"].init_source_term(1.0 / n)
+        if not stage("problem set-up", problem):
+            return give_up()
+        return box["s"]
 
     def run(s, warmup, steps):
         """W warm-up + K timed loop bodies on solver s.  Returns (elapsed, result) or None.  Every rank makes
@@ -355,7 +395,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, args.cpu_baseline_iters)
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
 
     solver.close()
     if dist is not None:
