@@ -7,4 +7,5 @@ Contents: csrc/ (HIP kernels + the C ABI of include/cgx.h), host/ (C++ CGSolver 
 cgx.py (ctypes binding used by tests/ and bench.py).  No CPU fallback anywhere in this package.
 """
 from . import cgx  # noqa: F401
-from .cgx import CGSolver, CgxError, COMM_SELF, COMM_LOOPBACK, COMM_RCCL, COMM_P2P, partition, comm_unique_id  # noqa: F401
+from .cgx import (CGSolver, CgxError, COMM_SELF, COMM_LOOPBACK, COMM_RCCL, COMM_P2P, MATRIX_DENSE, MATRIX_BANDED,  # noqa: F401
+                  partition, comm_unique_id)

@@ -16,12 +16,15 @@ UNIQUE_ID_BYTES = 128
 
 IPC_HANDLE_BYTES = 64
 COMM_SELF, COMM_LOOPBACK, COMM_RCCL, COMM_P2P = 0, 1, 2, 3
+MATRIX_DENSE, MATRIX_BANDED = 0, 1   # BANDED: opt-in fast path, not the reference's storage (include/cgx.h)
+MAX_DIAGONALS = 64
 
 EXPORTS = [
     "cgx_config_init", "cgx_comm_unique_id", "cgx_create", "cgx_destroy", "cgx_last_error", "cgx_status_string",
     "cgx_p2p_export", "cgx_p2p_import", "cgx_p2p_selftest",
     "cgx_partition", "cgx_generate_lap2d_matrix", "cgx_set_matrix_dense", "cgx_read_matrix",
     "cgx_init_source_term", "cgx_set_source_term", "cgx_set_max_iter", "cgx_set_tolerance", "cgx_get_size",
+    "cgx_get_matrix_format",
     "cgx_solve", "cgx_solve_begin", "cgx_solve_steps", "cgx_solve_end",
     "cgx_probe_gemv", "cgx_probe_time_gemv", "cgx_probe_vector_ops", "cgx_probe_get_matrix_rows",
 ]
@@ -33,7 +36,7 @@ class Config(C.Structure):
         ("nranks", C.c_int), ("unique_id", C.c_ubyte * UNIQUE_ID_BYTES), ("gemv_variant", C.c_int),
         ("lda_pad", C.c_int), ("check_every", C.c_int), ("profile_gemv", C.c_int), ("reserved0", C.c_int),
         ("p2p_mailbox_kib", C.c_int), ("p2p_timeout_ms", C.c_int), ("p2p_separate_exchange", C.c_int),
-        ("reserved", C.c_int * 5),
+        ("matrix_format", C.c_int), ("reserved", C.c_int * 4),
     ]
 
 
@@ -98,6 +101,7 @@ def lib():
         L.cgx_set_max_iter.argtypes = [vp, C.c_int]
         L.cgx_set_tolerance.argtypes = [vp, C.c_double]
         L.cgx_get_size.argtypes = [vp, ip, ip]
+        L.cgx_get_matrix_format.argtypes = [vp, C.c_int, ip, ip, ip, dp]
         L.cgx_solve.argtypes = [vp, dp, C.POINTER(Result)]
         L.cgx_solve_begin.argtypes = [vp, dp]
         L.cgx_solve_steps.argtypes = [vp, C.c_int, ip]
@@ -145,7 +149,7 @@ class CGSolver:
 
     def __init__(self, comm_mode=COMM_SELF, nranks=1, rank=0, device=0, unique_id=None, gemv_variant=0,
                  lda_pad=-1, check_every=0, profile_gemv=False, p2p_timeout_ms=0, p2p_mailbox_kib=0,
-                 p2p_separate_exchange=False):
+                 p2p_separate_exchange=False, matrix_format=MATRIX_DENSE):
         L = lib()
         cfg = Config()
         L.cgx_config_init(C.byref(cfg))
@@ -160,6 +164,7 @@ class CGSolver:
         cfg.p2p_timeout_ms = p2p_timeout_ms
         cfg.p2p_mailbox_kib = p2p_mailbox_kib
         cfg.p2p_separate_exchange = 1 if p2p_separate_exchange else 0
+        cfg.matrix_format = matrix_format
         if unique_id is not None:
             assert len(unique_id) == UNIQUE_ID_BYTES
             C.memmove(cfg.unique_id, bytes(unique_id), UNIQUE_ID_BYTES)
@@ -209,6 +214,13 @@ class CGSolver:
         ok = C.c_int()
         self._check(lib().cgx_p2p_selftest(self._h, int(rounds), C.byref(ok)))
         return bool(ok.value)
+
+    def matrix_format(self, local_shard=0):
+        """(format, offsets, device bytes) of a local shard's row block; offsets is [] for dense storage."""
+        fmt, nd, nbytes = C.c_int(), C.c_int(), C.c_double()
+        offs = (C.c_int * MAX_DIAGONALS)()
+        self._check(lib().cgx_get_matrix_format(self._h, int(local_shard), C.byref(fmt), C.byref(nd), offs, C.byref(nbytes)))
+        return fmt.value, list(offs[:nd.value]), nbytes.value
 
     # -- reference interface --------------------------------------------------------------------
     def generate_lap2d_matrix(self, size):

@@ -44,7 +44,8 @@ struct SegView {
 void seg_finalize(SegView *sv);
 
 struct GemvPlan {
-    int variant;     // 1 = column-split (p from L2 to registers), 2 = row-split (p tiles staged in LDS)
+    int variant;     // 1 = column-split (p from L2 to registers), 2 = row-split (p tiles staged in LDS),
+                     // 3 = banded storage (DiaView), one thread per row
     int R;           // rows per wave (variant 2) or per workgroup (variant 1)
     int U;           // column-step unroll
     int waves;       // waves per workgroup
@@ -73,7 +74,8 @@ hipError_t launch_gemv_fused(const GemvPlan &plan, const double *A, long lda, in
 // replicated, rv = [r (lda) | one r.r partial per K3 workgroup]); the next K1's head folds the partials.  cg.cc:105-116.
 hipError_t launch_update_xr(int n, int rows, int row0, const double *p_new, SegView apv, int tail_off, int tail_count,
                             double *x, SegView rv, Scalars *sc, int parity, double *partials, hipStream_t s);
-int update_xr_grid(int count);
+int update_xr_grid(int count);   // ceil(count/256), at most kMaxVectorGrid (above that the kernels stride over the rows)
+constexpr int kMaxVectorGrid = 1024;
 
 // Tail of the LAST executed iteration when the loop runs out (k = number of iterations done):
 // rsnew -> rs[k&1], convergence test (cg.cc:117-121,132).  One thread.
@@ -99,6 +101,37 @@ hipError_t launch_generate_lap2d(double *A, long lda, int size, int row0, int ro
 // Matrix::read scatter (matrix.cc:12-21): A[(I[z]-row0)*lda + J[z]] = a[z] for entries already filtered to this shard.
 hipError_t launch_scatter_coo(double *A, long lda, int row0, const int *I, const int *J, const double *a, long nz,
                               hipStream_t s);
+
+// ---- banded storage (opt-in, NOT the reference's dense contract: SURVEY.md section 8f.3) ------------------
+// The row block as its non-zero diagonals: vals[t*ld + i] = A(row0+i, row0+i+off[t]) for local row i, exactly 0
+// where that column lies outside [0,n).  Offsets ascending, so a row is summed in ascending column order.
+constexpr int kMaxDiags = 64;
+struct DiaView {
+    const double *vals;
+    long ld;              // >= rows
+    int ndiag;
+    int off[kMaxDiags];
+};
+GemvPlan plan_dia(int rows);   // variant 3, grid = min(ceil(rows/256), 2048)
+
+// K1 on banded storage: same contract as launch_gemv_plain / launch_gemv_fused (same iteration head, same p_new
+// = r + beta p_old, same one partial per workgroup), 8*(rows*ndiag) bytes of matrix instead of 8*rows*n.
+hipError_t launch_spmv_dia_plain(const GemvPlan &plan, const DiaView &dv, int rows, int row0, int n, const double *v_full,
+                                 double *Ap, double *partials, Scalars *sc, hipStream_t s);
+hipError_t launch_spmv_dia_fused(const GemvPlan &plan, const DiaView &dv, int rows, int row0, int n, long lda,
+                                 const double *p_old, double *p_new, SegView seg, double *Ap, double *partials,
+                                 Scalars *sc, int k, double tol, hipStream_t s);
+// generate_lap2d_matrix (cg.cc:159-188) straight into banded storage; dv.off must be lap2d_offsets(size).
+int lap2d_offsets(int size, int *off /* >= 5 */);
+hipError_t launch_dia_generate_lap2d(double *vals, const DiaView &dv, int size, int row0, int rows, hipStream_t s);
+// dense row block -> which diagonals hold a non-zero: flags[(j - i_global) + (n-1)] = 1
+hipError_t launch_dia_mark(const double *A, long lda, int n, int row0, int rows, unsigned char *flags, hipStream_t s);
+// dense row block -> banded storage for the offsets in dv
+hipError_t launch_dia_pack(const double *A, long lda, int n, int row0, int rows, double *vals, const DiaView &dv,
+                           hipStream_t s);
+// Matrix::read scatter into banded storage: vals[D[z]*ld + I[z]-row0] = a[z]
+hipError_t launch_dia_scatter_coo(double *vals, long ld, int row0, const int *I, const int *D, const double *a, long nz,
+                                  hipStream_t s);
 
 // ---- direct peer exchange (CGX_COMM_P2P): a lean all-gather over IPC-mapped mailboxes ---------------------
 // Every rank owns one fine-grained mailbox; all ranks map all mailboxes.  Layout (identical on every rank):

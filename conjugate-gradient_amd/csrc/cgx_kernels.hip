@@ -538,12 +538,11 @@ __global__ __launch_bounds__(256) void k_init_residual(int n, const double *__re
 {
     __shared__ double lds[4];
     double *r = rv.base;
-    const int i = blockIdx.x * 256 + threadIdx.x;
     double rr = 0.0;
-    if (i < n) {
-        const double rvv = b_full[i] - seg_load(apv, i);   // r = b - A x, cg.cc:79-82 (all rows: r is replicated)
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {   // one trip up to 256 Ki rows
+        const double rvv = b_full[i] - seg_load(apv, (int)i);   // r = b - A x, cg.cc:79-82 (all rows: r is replicated)
         r[i] = rvv;
-        rr = rvv * rvv;                                    // rsold = r.p with p == r, cg.cc:85,91
+        rr += rvv * rvv;                                        // rsold = r.p with p == r, cg.cc:85,91
     }
     rr = block_sum<4>(rr, lds);
     if (threadIdx.x == 0) r[rv.Sr + blockIdx.x] = rr;   // same slots as K3's partials: K1(0) folds them (cg.cc:91-92)
@@ -560,13 +559,12 @@ __global__ __launch_bounds__(256) void k_debug_norms(int count, const double *__
                                                       double *__restrict__ partials)
 {
     __shared__ double lds[4];
-    const int i = blockIdx.x * 256 + threadIdx.x;
     double e = 0.0, bb = 0.0, xx = 0.0;
-    if (i < count) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) {
         const double d = Ax[i] - b[i];     // cg.cc:146-148
-        e = d * d;
-        bb = b[i] * b[i];
-        xx = x[i] * x[i];
+        e += d * d;
+        bb += b[i] * b[i];
+        xx += x[i] * x[i];
     }
     e = block_sum<4>(e, lds);
     bb = block_sum<4>(bb, lds);
@@ -576,6 +574,17 @@ __global__ __launch_bounds__(256) void k_debug_norms(int count, const double *__
         partials[3 * blockIdx.x + 1] = bb;
         partials[3 * blockIdx.x + 2] = xx;
     }
+}
+
+// One entry of generate_lap2d_matrix, cg.cc:178-185 (0 <= i, j < size).
+__device__ __forceinline__ double lap2d_entry(int size, int inc, long i, long j)
+{
+    if (j == i) return 4.0;                                      // cg.cc:183
+    if (i > 0 && j == i - 1) return -1.0;                        // cg.cc:182
+    if (i < size - 1 && j == i + 1) return -1.0;                 // cg.cc:184
+    if (i > inc && j == i - 1 - inc) return -1.0;                // cg.cc:181
+    if (i < size - 1 - inc && j == i + 1 + inc) return -1.0;     // cg.cc:185
+    return 0.0;                                                  // cg.cc:178-180
 }
 
 // generate_lap2d_matrix, cg.cc:159-188.  One thread writes 16 B; rows are 16-B aligned (lda even).
@@ -592,15 +601,7 @@ __global__ __launch_bounds__(256) void k_generate_lap2d(double *__restrict__ A, 
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
             const int j = j0 + e;
-            double val = 0.0;                                               // cg.cc:178-180
-            if (j < size) {
-                if (j == i) val = 4.0;                                      // cg.cc:183
-                else if (i > 0 && j == i - 1) val = -1.0;                   // cg.cc:182
-                else if (i < size - 1 && j == i + 1) val = -1.0;            // cg.cc:184
-                else if (i > inc && j == i - 1 - inc) val = -1.0;           // cg.cc:181
-                else if (i < size - 1 - inc && j == i + 1 + inc) val = -1.0;// cg.cc:185
-            }
-            v[e] = val;
+            v[e] = (j < size) ? lap2d_entry(size, inc, i, j) : 0.0;
         }
         *reinterpret_cast<d2 *>(A + lr * lda + j0) = v;
     }
@@ -623,6 +624,129 @@ __global__ void k_loopback_gather(double *const *gathered_ptrs, const Scalars *c
         const int src = rem / kSlots, v = rem - src * kSlots;
         gathered_ptrs[dst][src * kSlots + v] = scalar_ptrs[src]->local[v];
     }
+}
+
+// K3 for vectors longer than 256 * kMaxVectorGrid rows (banded storage only: a dense matrix of that size does not
+// exist): the same arithmetic as k_update_xr with the workgroups striding over the rows, so that the number of r.r
+// partials every K1 workgroup folds stays bounded.
+__global__ __launch_bounds__(256) void k_update_xr_strided(int n, int rows, int row0, const double *__restrict__ p_new,
+                                                            SegView apv, int tail_off, int tail_count,
+                                                            double *__restrict__ x, SegView rv, Scalars *sc, int parity)
+{
+    __shared__ double lds[4];
+    double *r = rv.base;
+    const int done = sc->done;
+    const double rsold = sc->rs[parity];
+    double cs = 0.0;
+    for (int q = 0; q < apv.nranks; ++q) {
+        const double *tail = apv.base + (long)q * apv.S + apv.Sr + tail_off;
+        for (int j = threadIdx.x; j < tail_count; j += 256) cs += tail[j];
+    }
+    if (done) return;
+    const double conj = block_sum<4>(cs, lds);
+    const double alpha = rsold / fmax(conj, rsold * kNearZero);      // cg.cc:107
+    double rr = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const double rn = fma(-alpha, seg_load(apv, (int)i), r[i]);   // cg.cc:113
+        r[i] = rn;
+        rr += rn * rn;                                                // cg.cc:116
+        const long li = i - row0;
+        if (li >= 0 && li < rows) x[li] = fma(alpha, p_new[i], x[li]);   // cg.cc:110
+    }
+    rr = block_sum<4>(rr, lds);
+    if (threadIdx.x == 0) r[rv.Sr + blockIdx.x] = rr;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Banded storage (opt-in fast path; NOT the reference's dense GEMV contract).
+// K1 on the diagonals of the row block: one thread per row, diagonals in ascending offset order (= ascending
+// column order), every load coalesced: vals[t][i..i+63] and p[g+off .. g+off+63].  Same head, same p_new, same
+// one-partial-per-workgroup contract as the dense K1, so K3, the exchange and the host loop are shared.
+// Out-of-range columns are clamped instead of branched around: their stored value is exactly 0.
+// ------------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void k_spmv_dia(DiaView dv, int rows, int row0_global, int n, long lda,
+                                                   const double *__restrict__ v, double *__restrict__ p_new, SegView sv,
+                                                   double *__restrict__ Ap, double *__restrict__ partials, Scalars *sc,
+                                                   int k, double tol)
+{
+    constexpr bool FUSED = MODE != kPlain;
+    __shared__ double lds[4];
+    const double *rfull = sv.base;   // FUSED: the replicated r, zero padded up to lda
+    double beta = 0.0;
+    if constexpr (FUSED) {
+        const int done = sc->done;
+        const IterHead h = iteration_head<4>(sc, sv, k, tol, lds);
+        if (done || h.stop) return;
+        beta = h.beta;
+        // p_new = r + beta p_old (cg.cc:127-129), stored once: the grid strides over all lda columns
+        for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < lda; c += (long)gridDim.x * 256)
+            p_new[c] = fma(beta, v[c], rfull[c]);
+    }
+    double d = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows; i += (long)gridDim.x * 256) {
+        const long g = row0_global + i;
+        double acc = 0.0;
+#pragma unroll 4
+        for (int t = 0; t < dv.ndiag; ++t) {
+            long j = g + dv.off[t];
+            j = j < 0 ? 0 : (j > n - 1 ? n - 1 : j);
+            double pj = v[j];
+            if constexpr (FUSED) pj = fma(beta, pj, rfull[j]);   // same bits as the stored p_new[j]
+            acc = fma(dv.vals[t * dv.ld + i], pj, acc);          // cg.cc:100-102
+        }
+        Ap[i] = acc;
+        double pi = v[g];
+        if constexpr (FUSED) pi = fma(beta, pi, rfull[g]);
+        d = fma(pi, acc, d);                                     // cg.cc:105
+    }
+    d = block_sum<4>(d, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = d;
+}
+
+// generate_lap2d_matrix (cg.cc:159-188) straight into banded storage.
+__global__ __launch_bounds__(256) void k_dia_generate_lap2d(double *__restrict__ vals, DiaView dv, int size, int row0,
+                                                             int rows, int inc)
+{
+    const long total = (long)dv.ndiag * rows;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int t = (int)(idx / rows);
+        const long i = idx - (long)t * rows;
+        const long g = row0 + i, j = g + dv.off[t];
+        vals[t * dv.ld + i] = (j >= 0 && j < size) ? lap2d_entry(size, inc, g, j) : 0.0;
+    }
+}
+
+// Which diagonals of a dense row block hold a non-zero?  flags[(j - i_global) + n - 1] = 1 (same value from every
+// writer, so the race is benign).
+__global__ __launch_bounds__(256) void k_dia_mark(const double *__restrict__ A, long lda, int n, int row0, int rows,
+                                                   unsigned char *__restrict__ flags)
+{
+    const long total = (long)rows * n;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const long i = idx / n, j = idx - i * n;
+        if (A[i * lda + j] != 0.0) flags[j - (row0 + i) + (n - 1)] = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dia_pack(const double *__restrict__ A, long lda, int n, int row0, int rows,
+                                                   double *__restrict__ vals, DiaView dv)
+{
+    const long total = (long)dv.ndiag * rows;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int t = (int)(idx / rows);
+        const long i = idx - (long)t * rows;
+        const long j = row0 + i + dv.off[t];
+        vals[t * dv.ld + i] = (j >= 0 && j < n) ? A[i * lda + j] : 0.0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_dia_scatter_coo(double *__restrict__ vals, long ld, int row0,
+                                                          const int *__restrict__ I, const int *__restrict__ D,
+                                                          const double *__restrict__ a, long nz)
+{
+    for (long z = (long)blockIdx.x * 256 + threadIdx.x; z < nz; z += (long)gridDim.x * 256)
+        vals[(long)D[z] * ld + (I[z] - row0)] = a[z];    // matrix.cc:17 (duplicates resolved on the host)
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -949,13 +1073,100 @@ hipError_t launch_gemv_fused(const GemvPlan &pl, const double *A, long lda, int 
     return dispatch_gemv<kFusedSingle>(pl, g, s);
 }
 
-int update_xr_grid(int count) { return count > 0 ? ceil_div(count, 256) : 1; }
+int update_xr_grid(int count)
+{
+    const int g = count > 0 ? ceil_div(count, 256) : 1;
+    return g < kMaxVectorGrid ? g : kMaxVectorGrid;
+}
 
 hipError_t launch_update_xr(int n, int rows, int row0, const double *p_new, SegView apv, int tail_off, int tail_count,
                             double *x, SegView rv, Scalars *sc, int parity, double *partials, hipStream_t s)
 {
-    hipLaunchKernelGGL(k_update_xr, dim3(update_xr_grid(n)), dim3(256), 0, s, n, rows, row0, p_new, apv, tail_off,
-                       tail_count, x, rv, sc, parity, partials);
+    if ((long)update_xr_grid(n) * 256 >= n)   // one row per thread: every dense problem
+        hipLaunchKernelGGL(k_update_xr, dim3(update_xr_grid(n)), dim3(256), 0, s, n, rows, row0, p_new, apv, tail_off,
+                           tail_count, x, rv, sc, parity, partials);
+    else
+        hipLaunchKernelGGL(k_update_xr_strided, dim3(update_xr_grid(n)), dim3(256), 0, s, n, rows, row0, p_new, apv,
+                           tail_off, tail_count, x, rv, sc, parity);
+    return hipGetLastError();
+}
+
+GemvPlan plan_dia(int rows)
+{
+    GemvPlan pl{};
+    pl.variant = 3;
+    pl.R = 1;
+    pl.U = 1;
+    pl.waves = 4;
+    pl.rows_per_wg = 256;
+    pl.grid = rows > 0 ? ceil_div(rows, 256) : 1;
+    if (pl.grid > 2048) pl.grid = 2048;   // above that the workgroups stride: K3 folds at most 2048 partials per rank
+    return pl;
+}
+
+hipError_t launch_spmv_dia_plain(const GemvPlan &pl, const DiaView &dv, int rows, int row0, int n, const double *v_full,
+                                 double *Ap, double *partials, Scalars *sc, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_spmv_dia<kPlain>), dim3(pl.grid), dim3(256), 0, s, dv, rows, row0, n, 0L, v_full, nullptr,
+                       SegView{}, Ap, partials, sc, 0, 0.0);
+    return hipGetLastError();
+}
+
+hipError_t launch_spmv_dia_fused(const GemvPlan &pl, const DiaView &dv, int rows, int row0, int n, long lda,
+                                 const double *p_old, double *p_new, SegView seg, double *Ap, double *partials,
+                                 Scalars *sc, int k, double tol, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_spmv_dia<kFusedSingle>), dim3(pl.grid), dim3(256), 0, s, dv, rows, row0, n, lda, p_old, p_new,
+                       seg, Ap, partials, sc, k, tol);
+    return hipGetLastError();
+}
+
+int lap2d_offsets(int size, int *off)
+{
+    const int inc = (int)floor(sqrt((double)size));   // cg.cc:175
+    const int cand[5] = {-(inc + 1), -1, 0, 1, inc + 1};
+    int nd = 0;
+    for (int c : cand)
+        if (c > -size && c < size) off[nd++] = c;
+    return nd;
+}
+
+static inline int capped_grid(long total, int cap)
+{
+    const long g = (total + 255) / 256;
+    return (int)(g < 1 ? 1 : (g < cap ? g : cap));
+}
+
+hipError_t launch_dia_generate_lap2d(double *vals, const DiaView &dv, int size, int row0, int rows, hipStream_t s)
+{
+    if (rows <= 0) return hipSuccess;
+    const int inc = (int)floor(sqrt((double)size));
+    hipLaunchKernelGGL(k_dia_generate_lap2d, dim3(capped_grid((long)dv.ndiag * rows, 8192)), dim3(256), 0, s, vals, dv, size,
+                       row0, rows, inc);
+    return hipGetLastError();
+}
+
+hipError_t launch_dia_mark(const double *A, long lda, int n, int row0, int rows, unsigned char *flags, hipStream_t s)
+{
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_dia_mark, dim3(capped_grid((long)rows * n, 16384)), dim3(256), 0, s, A, lda, n, row0, rows, flags);
+    return hipGetLastError();
+}
+
+hipError_t launch_dia_pack(const double *A, long lda, int n, int row0, int rows, double *vals, const DiaView &dv,
+                           hipStream_t s)
+{
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_dia_pack, dim3(capped_grid((long)dv.ndiag * rows, 8192)), dim3(256), 0, s, A, lda, n, row0, rows,
+                       vals, dv);
+    return hipGetLastError();
+}
+
+hipError_t launch_dia_scatter_coo(double *vals, long ld, int row0, const int *I, const int *D, const double *a, long nz,
+                                  hipStream_t s)
+{
+    if (nz <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_dia_scatter_coo, dim3(capped_grid(nz, 2048)), dim3(256), 0, s, vals, ld, row0, I, D, a, nz);
     return hipGetLastError();
 }
 

@@ -48,7 +48,9 @@ struct Shard {
     int rank = 0;
     int row0 = 0;
     int rows = 0;
-    double *A = nullptr;         // rows x lda, row-major, pad columns zero
+    double *A = nullptr;         // rows x lda, row-major, pad columns zero (CGX_MATRIX_DENSE)
+    double *dia_vals = nullptr;  // CGX_MATRIX_BANDED: ndiag x dia.ld, the non-zero diagonals of the row block
+    cgx::DiaView dia{};
     double *b_full = nullptr;    // n doubles: b is replicated like r (the reference builds the full b on every rank, cg.cc:218-234)
     double *x = nullptr;         // rows
     double *p[2] = {nullptr, nullptr};   // lda doubles each: the replicated p (cg.cc:57), ping-pong over iterations
@@ -79,6 +81,7 @@ struct cgx_ctx {
     std::vector<Shard> shards;   // 1 (SELF / RCCL) or nranks (LOOPBACK)
     std::vector<double> b_host;
     bool have_matrix = false, have_b = false;
+    bool banded = false;         // cfg.matrix_format == CGX_MATRIX_BANDED (opt-in, not the reference's storage)
 
     // RCCL
     const cgx::RcclApi *rccl = nullptr;
@@ -168,6 +171,7 @@ void partition_rows(int N, int psize, int *start_rows, int *num_rows)
 void free_shard(Shard &s)
 {
     (void)hipFree(s.A);
+    (void)hipFree(s.dia_vals);
     (void)hipFree(s.b_full);
     (void)hipFree(s.x);
     (void)hipFree(s.p[0]);
@@ -215,6 +219,7 @@ long default_lda(const cgx_ctx *ctx, int n)
 cgx_status setup_problem(cgx_ctx *ctx, int n)
 {
     if (n <= 0) return fail(ctx, CGX_ERR_BAD_ARG, "matrix size must be positive");
+    if (n > (1 << 30)) return fail(ctx, CGX_ERR_UNSUPPORTED, "matrix size above 2^30 (indices are int, like the reference's)");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (!ctx->shards.empty() && ctx->n == n && ctx->lda == default_lda(ctx, n)) {
         // Same geometry as the current problem: keep every buffer.  (Freeing and re-allocating a multi-GiB matrix
@@ -247,9 +252,12 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
         const char *e = getenv("CGX_GEMV_VARIANT");
         if (e) variant = atoi(e);
     }
+    auto plan_for = [&](int rows) { return ctx->banded ? cgx::plan_dia(rows) : cgx::plan_gemv(variant, rows, (int)ctx->lda); };
     ctx->npart = 1;
-    for (int q = 0; q < ctx->nranks; ++q)
-        ctx->npart = std::max(ctx->npart, cgx::plan_gemv(variant, ctx->num_rows[q], (int)ctx->lda).grid);
+    for (int q = 0; q < ctx->nranks; ++q) ctx->npart = std::max(ctx->npart, plan_for(ctx->num_rows[q]).grid);
+    if (ctx->cfg.comm_mode == CGX_COMM_P2P && n > 256 * cgx::kMaxVectorGrid)
+        return fail(ctx, CGX_ERR_UNSUPPORTED, "CGX_COMM_P2P handles at most 262144 rows (the update kernel with the exchange "
+                                              "inside works one row per thread); use CGX_COMM_RCCL");
     if (ctx->cfg.comm_mode == CGX_COMM_P2P) {
         // mailbox layout of this problem: flags, then per channel [2 parities][nranks] slots
         // The small fixed-size channels come first, so that their place never depends on the problem; the
@@ -278,10 +286,10 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
         s.rank = (ctx->cfg.comm_mode == CGX_COMM_RCCL || ctx->cfg.comm_mode == CGX_COMM_P2P) ? ctx->cfg.rank : i;
         s.row0 = ctx->start_rows[s.rank];
         s.rows = ctx->num_rows[s.rank];
-        s.plan = cgx::plan_gemv(variant, s.rows, (int)ctx->lda);
+        s.plan = plan_for(s.rows);
         const size_t rows_alloc = (size_t)std::max(s.rows, 1);
         s.npartials = 3 * cgx::update_xr_grid(n) + 8;
-        HIP_TRY(ctx, hipMalloc(&s.A, rows_alloc * (size_t)ctx->lda * sizeof(double)));
+        if (!ctx->banded) HIP_TRY(ctx, hipMalloc(&s.A, rows_alloc * (size_t)ctx->lda * sizeof(double)));
         HIP_TRY(ctx, hipMalloc(&s.b_full, (size_t)n * sizeof(double)));
         HIP_TRY(ctx, hipMalloc(&s.x, rows_alloc * sizeof(double)));
         HIP_TRY(ctx, hipMalloc(&s.p[0], (size_t)ctx->lda * sizeof(double)));
@@ -302,7 +310,7 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
         HIP_TRY(ctx, hipMemsetAsync(s.p[1], 0, (size_t)ctx->lda * sizeof(double), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(s.apg, 0, apg_bytes, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(s.rbuf, 0, rbuf_bytes, ctx->stream));
-        if (s.rows <= 0) HIP_TRY(ctx, hipMemsetAsync(s.A, 0, (size_t)ctx->lda * sizeof(double), ctx->stream));
+        if (s.rows <= 0 && s.A) HIP_TRY(ctx, hipMemsetAsync(s.A, 0, (size_t)ctx->lda * sizeof(double), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(s.partials, 0, (size_t)s.npartials * sizeof(double), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(s.sc, 0, sizeof(Scalars), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(s.gathered, 0, (size_t)cgx::kMaxRanks * cgx::kSlots * sizeof(double), ctx->stream));
@@ -403,11 +411,36 @@ cgx_status take_event(cgx_ctx *ctx, hipEvent_t *out)
     return CGX_OK;
 }
 
+// CGX_MATRIX_BANDED: (re)allocate the diagonals of shard s for the given ascending offsets; contents zeroed.
+cgx_status alloc_dia(cgx_ctx *ctx, Shard &s, const std::vector<int> &offs)
+{
+    if ((int)offs.size() > CGX_MAX_DIAGONALS)
+        return fail(ctx, CGX_ERR_UNSUPPORTED, "row block of rank " + std::to_string(s.rank) + " has " +
+                                                  std::to_string(offs.size()) + " non-zero diagonals, more than " +
+                                                  std::to_string(CGX_MAX_DIAGONALS) +
+                                                  ": not a banded matrix (use CGX_MATRIX_DENSE)");
+    (void)hipFree(s.dia_vals);
+    s.dia_vals = nullptr;
+    s.dia = cgx::DiaView{};
+    s.dia.ld = ((long)std::max(s.rows, 1) + 1) / 2 * 2;
+    s.dia.ndiag = (int)offs.size();
+    for (int t = 0; t < s.dia.ndiag; ++t) s.dia.off[t] = offs[t];
+    const size_t bytes = (size_t)std::max(s.dia.ndiag, 1) * (size_t)s.dia.ld * sizeof(double);
+    HIP_TRY(ctx, hipMalloc(&s.dia_vals, bytes));
+    HIP_TRY(ctx, hipMemsetAsync(s.dia_vals, 0, bytes, ctx->stream));
+    s.dia.vals = s.dia_vals;
+    return CGX_OK;
+}
+
 // K1, plain form (vector given): initial residual, DEBUG verification, probes.
 cgx_status run_gemv_plain(cgx_ctx *ctx, Shard &s, const double *v_full)
 {
-    HIP_TRY(ctx, cgx::launch_gemv_plain(s.plan, s.A, ctx->lda, s.rows, v_full, v_full + s.row0, s.Ap(), s.k1_part(), s.sc,
-                                        ctx->stream));
+    if (ctx->banded)
+        HIP_TRY(ctx, cgx::launch_spmv_dia_plain(s.plan, s.dia, s.rows, s.row0, ctx->n, v_full, s.Ap(), s.k1_part(), s.sc,
+                                                ctx->stream));
+    else
+        HIP_TRY(ctx, cgx::launch_gemv_plain(s.plan, s.A, ctx->lda, s.rows, v_full, v_full + s.row0, s.Ap(), s.k1_part(),
+                                            s.sc, ctx->stream));
     return CGX_OK;
 }
 
@@ -422,8 +455,12 @@ cgx_status run_gemv_fused(cgx_ctx *ctx, Shard &s, int k)
         CGX_TRY(take_event(ctx, &e1));
         HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
     }
-    HIP_TRY(ctx, cgx::launch_gemv_fused(s.plan, s.A, ctx->lda, s.rows, s.row0, s.p[k & 1], s.p[(k + 1) & 1], s.rv, s.Ap(),
-                                        s.k1_part(), s.sc, k, ctx->tol, ctx->stream));
+    if (ctx->banded)
+        HIP_TRY(ctx, cgx::launch_spmv_dia_fused(s.plan, s.dia, s.rows, s.row0, ctx->n, ctx->lda, s.p[k & 1], s.p[(k + 1) & 1],
+                                                s.rv, s.Ap(), s.k1_part(), s.sc, k, ctx->tol, ctx->stream));
+    else
+        HIP_TRY(ctx, cgx::launch_gemv_fused(s.plan, s.A, ctx->lda, s.rows, s.row0, s.p[k & 1], s.p[(k + 1) & 1], s.rv,
+                                            s.Ap(), s.k1_part(), s.sc, k, ctx->tol, ctx->stream));
     if (timed) HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
     return CGX_OK;
 }
@@ -562,6 +599,8 @@ cgx_status cgx_create(cgx_ctx **out, const cgx_config *cfg_in)
         return fail(nullptr, CGX_ERR_BAD_ARG, "CGX_COMM_RCCL/P2P: rank out of range or nranks > 64");
     if (cfg.comm_mode < CGX_COMM_SELF || cfg.comm_mode > CGX_COMM_P2P)
         return fail(nullptr, CGX_ERR_BAD_ARG, "unknown comm_mode");
+    if (cfg.matrix_format != CGX_MATRIX_DENSE && cfg.matrix_format != CGX_MATRIX_BANDED)
+        return fail(nullptr, CGX_ERR_BAD_ARG, "unknown matrix_format");
 
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -575,6 +614,7 @@ cgx_status cgx_create(cgx_ctx **out, const cgx_config *cfg_in)
     ctx->cfg = cfg;
     ctx->device = cfg.device;
     ctx->nranks = cfg.nranks;
+    ctx->banded = cfg.matrix_format == CGX_MATRIX_BANDED;
     if (ctx->cfg.check_every <= 0) ctx->cfg.check_every = 16;
     if (getenv("CGX_P2P_SEPARATE_EXCHANGE")) ctx->cfg.p2p_separate_exchange = 1;
 
@@ -743,6 +783,20 @@ cgx_status cgx_get_size(const cgx_ctx *ctx, int *m, int *n)
     return CGX_OK;
 }
 
+cgx_status cgx_get_matrix_format(const cgx_ctx *ctx, int local_shard, int *format, int *ndiag, int *offsets,
+                                 double *matrix_bytes)
+{
+    if (!ctx || local_shard < 0 || local_shard >= (int)ctx->shards.size() || !ctx->have_matrix) return CGX_ERR_BAD_ARG;
+    const Shard &s = ctx->shards[local_shard];
+    if (format) *format = ctx->banded ? CGX_MATRIX_BANDED : CGX_MATRIX_DENSE;
+    if (ndiag) *ndiag = ctx->banded ? s.dia.ndiag : 0;
+    if (offsets && ctx->banded)
+        for (int t = 0; t < s.dia.ndiag; ++t) offsets[t] = s.dia.off[t];
+    if (matrix_bytes)
+        *matrix_bytes = ctx->banded ? 8.0 * (double)s.dia.ndiag * (double)s.dia.ld : 8.0 * (double)std::max(s.rows, 1) * (double)ctx->lda;
+    return CGX_OK;
+}
+
 cgx_status cgx_set_max_iter(cgx_ctx *ctx, int max_iter)
 {
     if (!ctx) return CGX_ERR_BAD_ARG;
@@ -762,8 +816,18 @@ cgx_status cgx_generate_lap2d_matrix(cgx_ctx *ctx, int size)
 {
     if (!ctx) return CGX_ERR_BAD_ARG;
     CGX_TRY(setup_problem(ctx, size));
-    for (auto &s : ctx->shards)
-        HIP_TRY(ctx, cgx::launch_generate_lap2d(s.A, ctx->lda, size, s.row0, s.rows, ctx->stream));
+    if (ctx->banded) {
+        // the five diagonals of cg.cc:181-185, written straight into banded storage: no n x n block ever exists
+        int off[5];
+        const int nd = cgx::lap2d_offsets(size, off);
+        for (auto &s : ctx->shards) {
+            CGX_TRY(alloc_dia(ctx, s, std::vector<int>(off, off + nd)));
+            HIP_TRY(ctx, cgx::launch_dia_generate_lap2d(s.dia_vals, s.dia, size, s.row0, s.rows, ctx->stream));
+        }
+    } else {
+        for (auto &s : ctx->shards)
+            HIP_TRY(ctx, cgx::launch_generate_lap2d(s.A, ctx->lda, size, s.row0, s.rows, ctx->stream));
+    }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_matrix = true;
     return CGX_OK;
@@ -775,11 +839,41 @@ cgx_status cgx_set_matrix_dense(cgx_ctx *ctx, const double *A, long lda_host, in
     if (!ctx || !A || lda_host < n) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_set_matrix_dense: bad argument");
     CGX_TRY(setup_problem(ctx, n));
     for (auto &s : ctx->shards) {
-        if (s.rows <= 0) continue;
-        HIP_TRY(ctx, hipMemsetAsync(s.A, 0, (size_t)s.rows * ctx->lda * sizeof(double), ctx->stream));
-        HIP_TRY(ctx, hipMemcpy2DAsync(s.A, (size_t)ctx->lda * sizeof(double), A + (size_t)s.row0 * lda_host,
+        if (s.rows <= 0) {
+            if (ctx->banded) CGX_TRY(alloc_dia(ctx, s, {}));
+            continue;
+        }
+        double *dst = s.A;
+        if (ctx->banded)   // staged densely for the scan only, freed below
+            HIP_TRY(ctx, hipMalloc(&dst, (size_t)s.rows * ctx->lda * sizeof(double)));
+        struct Staging {
+            double *p;
+            ~Staging() { (void)hipFree(p); }
+        } staging{ctx->banded ? dst : nullptr};
+        HIP_TRY(ctx, hipMemsetAsync(dst, 0, (size_t)s.rows * ctx->lda * sizeof(double), ctx->stream));
+        HIP_TRY(ctx, hipMemcpy2DAsync(dst, (size_t)ctx->lda * sizeof(double), A + (size_t)s.row0 * lda_host,
                                       (size_t)lda_host * sizeof(double), (size_t)n * sizeof(double), (size_t)s.rows,
                                       hipMemcpyHostToDevice, ctx->stream));
+        if (!ctx->banded) continue;
+        // which diagonals hold a non-zero (device scan), then pack them
+        const size_t nflags = 2 * (size_t)n - 1;
+        unsigned char *dflags = nullptr;
+        HIP_TRY(ctx, hipMalloc(&dflags, nflags));
+        struct Flags {
+            unsigned char *p;
+            ~Flags() { (void)hipFree(p); }
+        } flags_guard{dflags};
+        HIP_TRY(ctx, hipMemsetAsync(dflags, 0, nflags, ctx->stream));
+        HIP_TRY(ctx, cgx::launch_dia_mark(dst, ctx->lda, n, s.row0, s.rows, dflags, ctx->stream));
+        std::vector<unsigned char> hflags(nflags);
+        HIP_TRY(ctx, hipMemcpyAsync(hflags.data(), dflags, nflags, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        std::vector<int> offs;
+        for (size_t f = 0; f < nflags; ++f)
+            if (hflags[f]) offs.push_back((int)((long)f - (n - 1)));
+        CGX_TRY(alloc_dia(ctx, s, offs));
+        HIP_TRY(ctx, cgx::launch_dia_pack(dst, ctx->lda, n, s.row0, s.rows, s.dia_vals, s.dia, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_matrix = true;
@@ -863,8 +957,20 @@ cgx_status cgx_read_matrix(cgx_ctx *ctx, const char *path)
     for (size_t si = 0; si < ctx->shards.size(); ++si) {
         Shard &s = ctx->shards[si];
         Coo &c = coo[si];
+        if (ctx->banded) {
+            // the distinct (column - row) offsets of the stored entries are the diagonals; the scatter then takes
+            // the diagonal index in place of the column
+            std::vector<int> offs(c.J.size());
+            for (size_t z = 0; z < c.J.size(); ++z) offs[z] = c.J[z] - c.I[z];
+            std::sort(offs.begin(), offs.end());
+            offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
+            CGX_TRY(alloc_dia(ctx, s, offs));
+            for (size_t z = 0; z < c.J.size(); ++z)
+                c.J[z] = (int)(std::lower_bound(offs.begin(), offs.end(), c.J[z] - c.I[z]) - offs.begin());
+        }
         if (s.rows <= 0) continue;
-        HIP_TRY(ctx, hipMemsetAsync(s.A, 0, (size_t)s.rows * ctx->lda * sizeof(double), ctx->stream));  // Matrix::resize zero-fills
+        if (!ctx->banded)
+            HIP_TRY(ctx, hipMemsetAsync(s.A, 0, (size_t)s.rows * ctx->lda * sizeof(double), ctx->stream));  // Matrix::resize zero-fills
         const size_t cnt = c.a.size();
         if (!cnt) continue;
         int *dI = nullptr, *dJ = nullptr;
@@ -875,7 +981,10 @@ cgx_status cgx_read_matrix(cgx_ctx *ctx, const char *path)
         HIP_TRY(ctx, hipMemcpyAsync(dI, c.I.data(), cnt * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(dJ, c.J.data(), cnt * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemcpyAsync(da, c.a.data(), cnt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, cgx::launch_scatter_coo(s.A, ctx->lda, s.row0, dI, dJ, da, (long)cnt, ctx->stream));
+        if (ctx->banded)
+            HIP_TRY(ctx, cgx::launch_dia_scatter_coo(s.dia_vals, s.dia.ld, s.row0, dI, dJ, da, (long)cnt, ctx->stream));
+        else
+            HIP_TRY(ctx, cgx::launch_scatter_coo(s.A, ctx->lda, s.row0, dI, dJ, da, (long)cnt, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         (void)hipFree(dI);
         (void)hipFree(dJ);
@@ -1044,7 +1153,8 @@ cgx_status cgx_solve_end(cgx_ctx *ctx, double *x, cgx_result *res)
         res->gemv_launches = ctx->gemv_launches;
         res->gemv_ms_avg = ctx->gemv_launches ? ctx->gemv_ms_sum / (double)ctx->gemv_launches : 0.0;
         res->gemv_ms_min = ctx->gemv_ms_min;
-        res->gemv_bytes = 8.0 * ((double)s0.rows * ctx->n + ctx->n + s0.rows);
+        res->gemv_bytes = ctx->banded ? 8.0 * ((double)s0.rows * s0.dia.ndiag + 2.0 * s0.rows)
+                                      : 8.0 * ((double)s0.rows * ctx->n + ctx->n + s0.rows);
     }
     return CGX_OK;
 }
@@ -1179,7 +1289,18 @@ cgx_status cgx_probe_get_matrix_rows(cgx_ctx *ctx, int local_shard, double *A_ou
     Shard &s = ctx->shards[local_shard];
     if (row0) *row0 = s.row0;
     if (rows) *rows = s.rows;
-    if (A_out && s.rows > 0) {
+    if (A_out && s.rows > 0 && ctx->banded) {
+        // expand the diagonals on the host (a test probe, small sizes)
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        std::vector<double> vals((size_t)std::max(s.dia.ndiag, 1) * (size_t)s.dia.ld);
+        HIP_TRY(ctx, hipMemcpy(vals.data(), s.dia_vals, vals.size() * sizeof(double), hipMemcpyDeviceToHost));
+        std::fill(A_out, A_out + (size_t)s.rows * ctx->n, 0.0);
+        for (int t = 0; t < s.dia.ndiag; ++t)
+            for (int i = 0; i < s.rows; ++i) {
+                const long j = (long)s.row0 + i + s.dia.off[t];
+                if (j >= 0 && j < ctx->n) A_out[(size_t)i * ctx->n + (size_t)j] = vals[(size_t)t * s.dia.ld + i];
+            }
+    } else if (A_out && s.rows > 0) {
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         HIP_TRY(ctx, hipMemcpy2D(A_out, (size_t)ctx->n * sizeof(double), s.A, (size_t)ctx->lda * sizeof(double),
                                  (size_t)ctx->n * sizeof(double), (size_t)s.rows, hipMemcpyDeviceToHost));

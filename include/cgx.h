@@ -53,6 +53,19 @@ typedef enum cgx_comm_mode {
                                  all); needs cgx_p2p_export / cgx_p2p_import after cgx_create                 */
 } cgx_comm_mode;
 
+/* How the row block is held on the device.  DENSE is the reference's contract (Matrix, code/MPI/matrix.hh:7-29:
+ * every one of the n*n entries is stored and streamed by the GEMV) and the only format bench.py measures.
+ * BANDED is an OPT-IN fast path that is NOT in the reference: the block is held as its non-zero diagonals (at
+ * most CGX_MAX_DIAGONALS of them) and K1 becomes a banded mat-vec -- same CG recurrence, same results to rounding,
+ * n/ndiag times less matrix traffic (the reference's unused MatrixCOO::mat_vec,
+ * code/MPI/matrix_coo.hh:22-34, is the hint).  A matrix with more diagonals is refused with
+ * CGX_ERR_UNSUPPORTED, never silently densified. */
+typedef enum cgx_matrix_format {
+    CGX_MATRIX_DENSE = 0,
+    CGX_MATRIX_BANDED = 1
+} cgx_matrix_format;
+#define CGX_MAX_DIAGONALS 64
+
 typedef struct cgx_config {
     int  struct_version;      /* = CGX_VERSION                                              */
     int  comm_mode;           /* cgx_comm_mode                                              */
@@ -68,7 +81,8 @@ typedef struct cgx_config {
     int  p2p_mailbox_kib;     /* CGX_COMM_P2P: mailbox size in KiB (0 = 4096)               */
     int  p2p_timeout_ms;      /* CGX_COMM_P2P: bound of every in-kernel wait (0 = 5000)     */
     int  p2p_separate_exchange; /* CGX_COMM_P2P: 1 = exchange in its own kernel between K1 and K3 (default 0: folded into K3) */
-    int  reserved[5];
+    int  matrix_format;       /* cgx_matrix_format; 0 = dense = the reference's storage     */
+    int  reserved[4];
 } cgx_config;
 
 typedef struct cgx_result {
@@ -83,7 +97,7 @@ typedef struct cgx_result {
     double gemv_ms_avg;       /* mean K1 launch duration (HIP events), 0 if not profiled    */
     double gemv_ms_min;
     long long gemv_launches;  /* K1 launches that were event-timed                          */
-    double gemv_bytes;        /* algorithmic bytes of ONE K1 launch on this shard: 8*(rows*n + n + rows) */
+    double gemv_bytes;        /* algorithmic bytes of ONE K1 launch on this shard: 8*(rows*n + n + rows); banded: 8*(rows*ndiag + 2*rows) */
     double reserved[4];
 } cgx_result;
 
@@ -130,6 +144,10 @@ cgx_status  cgx_set_source_term(cgx_ctx *ctx, const double *b /* n doubles */);
 cgx_status  cgx_set_max_iter(cgx_ctx *ctx, int max_iter);
 cgx_status  cgx_set_tolerance(cgx_ctx *ctx, double tol);
 cgx_status  cgx_get_size(const cgx_ctx *ctx, int *m, int *n);   /* CGSolver::m(), n() */
+/* Storage of local shard `local_shard`: *format = cgx_matrix_format; banded: *ndiag and offsets[0..*ndiag)
+ * (column minus row, ascending; room for CGX_MAX_DIAGONALS ints or NULL); *matrix_bytes = device bytes of the block. */
+cgx_status  cgx_get_matrix_format(const cgx_ctx *ctx, int local_shard, int *format, int *ndiag, int *offsets,
+                                  double *matrix_bytes);
 
 /* ---- CGSolver::solve, cg.cc:38-156 ------------------------------------------------------- */
 /* x: n doubles, in = initial guess (cg_main.cc:49-50 passes zeros), out = solution (every rank
@@ -155,7 +173,7 @@ cgx_status  cgx_probe_time_gemv(cgx_ctx *ctx, int reps, double *ms_per_launch);
  * data of length n, single shard: x += alpha p; r -= alpha Ap; *rr = r.r; p = r + beta p. */
 cgx_status  cgx_probe_vector_ops(cgx_ctx *ctx, int n, double alpha, double beta, double *x, double *r,
                                  double *p, const double *Ap, double *rr);
-/* Copy this shard's device row block (rows x n, dense, row-major) back to the host. */
+/* Copy this shard's device row block (rows x n, dense, row-major) back to the host (banded storage is expanded). */
 cgx_status  cgx_probe_get_matrix_rows(cgx_ctx *ctx, int local_shard, double *A_out, int *row0, int *rows);
 
 #ifdef __cplusplus

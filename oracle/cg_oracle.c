@@ -137,11 +137,33 @@ void oracle_axpy(int n, double a, const double *x, double *y)
 /* ---- code/MPI/cg.cc:38-156 : CGSolver::solve ------------------------------------------ */
 
 typedef struct {
-    const double *A;   /* row block, ld = n */
+    const double *A;   /* row block, ld = n; NULL = the generate_lap2d rule applied on the fly (banded twin) */
     int start, count;
     double *r, *x, *Ap, *p, *tmp;   /* *_sub vectors, cg.cc:71-75 */
     double part;                    /* this rank's contribution to the pending reduction */
 } rank_state;
+
+/* Ap_sub = A_sub * v for one rank (cblas_dgemv, cg.cc:80-81,101-102,146-147).  With no stored block the five
+ * entries of row i are taken from the generator's rule (cg.cc:181-185) in ascending column order: the same
+ * matrix, never materialised -- used only where a dense n x n block cannot exist (oracle_solve_lap2d_banded). */
+static void block_matvec(const rank_state *s, int n, const double *v)
+{
+    if (s->A) {
+        oracle_gemv(s->count, n, s->A, n, v, s->Ap);
+        return;
+    }
+    const int inc = (int)floor(sqrt((double)n));                   /* cg.cc:175 */
+    for (int li = 0; li < s->count; ++li) {
+        const int i = s->start + li;
+        double acc = 0.0;
+        if (i > inc) acc += -1.0 * v[i - 1 - inc];                  /* cg.cc:181 */
+        if (i > 0) acc += -1.0 * v[i - 1];                          /* cg.cc:182 */
+        acc += 4.0 * v[i];                                          /* cg.cc:183 */
+        if (i < n - 1) acc += -1.0 * v[i + 1];                      /* cg.cc:184 */
+        if (i < n - 1 - inc) acc += -1.0 * v[i + 1 + inc];          /* cg.cc:185 */
+        s->Ap[li] = acc;
+    }
+}
 
 /* Row blocks may be worked on by several host threads (the reference's MPI ranks, cg.run: srun -n P): every
  * loop over ranks below is embarrassingly parallel; the reductions over ranks stay sequential, in rank order,
@@ -160,7 +182,7 @@ static int solve_blocks(rank_state *rk, int psize, const double *b, double *x, i
         rank_state *s = &rk[q];
         memcpy(s->r, b + s->start, (size_t)s->count * sizeof(double));
         memcpy(s->x, x + s->start, (size_t)s->count * sizeof(double));
-        oracle_gemv(s->count, n, s->A, n, x, s->Ap);
+        block_matvec(s, n, x);
         oracle_axpy(s->count, -1.0, s->Ap, s->r);
         memcpy(s->p, s->r, (size_t)s->count * sizeof(double));            /* cg.cc:85 */
         memcpy(p + s->start, s->p, (size_t)s->count * sizeof(double));    /* Allgatherv, cg.cc:87-88 */
@@ -178,7 +200,7 @@ static int solve_blocks(rank_state *rk, int psize, const double *b, double *x, i
 #pragma omp parallel for num_threads(g_threads) schedule(static) if (g_threads > 1)
         for (int q = 0; q < psize; ++q) {
             rank_state *s = &rk[q];
-            oracle_gemv(s->count, n, s->A, n, p, s->Ap);                  /* cg.cc:100-102 */
+            block_matvec(s, n, p);                                        /* cg.cc:100-102 */
             s->part = oracle_dot(s->count, s->p, s->Ap);                  /* cg.cc:105 */
         }
         for (int q = 0; q < psize; ++q) conj += rk[q].part;              /* MPI_Allreduce, cg.cc:106 */
@@ -214,7 +236,7 @@ static int solve_blocks(rank_state *rk, int psize, const double *b, double *x, i
     double rr = 0.0;
     for (int q = 0; q < psize; ++q) {
         rank_state *s = &rk[q];
-        oracle_gemv(s->count, n, s->A, n, x, s->Ap);
+        block_matvec(s, n, x);
         for (int i = 0; i < s->count; ++i) {
             double d = s->Ap[i] - b[s->start + i];
             s->Ap[i] = d;
@@ -302,6 +324,29 @@ int oracle_solve_lap2d(int n, int max_iter, double tol, int psize, double *x, or
     if (!rc) rc = solve_blocks(rk, psize, b, x, n, max_iter, tol, res);
     for (int q = 0; q < psize; ++q) { free_rank_vectors(&rk[q]); free(blocks[q]); }
     free(blocks); free(b); free(rk); free(start); free(num);
+    return rc;
+}
+
+int oracle_solve_lap2d_banded(int n, int max_iter, double tol, int psize, double *x, oracle_result *res)
+{
+    if (!x || n <= 0 || psize <= 0) return -2;
+    int *start = (int *)malloc(sizeof(int) * (size_t)psize);
+    int *num = (int *)malloc(sizeof(int) * (size_t)psize);
+    rank_state *rk = (rank_state *)calloc((size_t)psize, sizeof(rank_state));
+    double *b = (double *)malloc((size_t)n * sizeof(double));
+    if (!start || !num || !rk || !b) return -1;
+    oracle_partition(n, psize, start, num);
+    oracle_init_source_term(n, 1. / n, b);                                /* cg_main.cc:45-46 */
+    int rc = 0;
+    for (int q = 0; q < psize; ++q) {
+        rk[q].A = NULL;                                                   /* rule applied on the fly */
+        rk[q].start = start[q];
+        rk[q].count = num[q];
+        if (alloc_rank_vectors(&rk[q])) rc = -1;
+    }
+    if (!rc) rc = solve_blocks(rk, psize, b, x, n, max_iter, tol, res);
+    for (int q = 0; q < psize; ++q) free_rank_vectors(&rk[q]);
+    free(b); free(rk); free(start); free(num);
     return rc;
 }
 

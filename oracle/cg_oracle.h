@@ -58,6 +58,11 @@ void oracle_set_threads(int nthreads);
  * allocates psize row blocks itself with oracle_generate_lap2d_rows (used for large N). */
 int oracle_solve_lap2d(int n, int max_iter, double tol, int psize, double *x, oracle_result *res);
 
+/* The same solve with the generator's rule (cg.cc:181-185) applied on the fly instead of a stored n x n block:
+ * the checker for libcgx's opt-in banded storage at sizes where the dense block cannot exist.  It is validated
+ * against oracle_solve_lap2d at small n (tests/test_oracle.py); it is not a path of the reference. */
+int oracle_solve_lap2d_banded(int n, int max_iter, double tol, int psize, double *x, oracle_result *res);
+
 /* y = A[0:m, 0:n] * x, row-major, lda -- the cblas_dgemv call at cg.cc:101-102 */
 void oracle_gemv(int m, int n, const double *A, long lda, const double *x, double *y);
 double oracle_dot(int n, const double *x, const double *y);            /* cg.cc:105,116 */

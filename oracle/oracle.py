@@ -60,6 +60,8 @@ def lib():
         L.oracle_solve.restype = C.c_int
         L.oracle_solve_lap2d.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, dp, C.POINTER(OracleResult)]
         L.oracle_solve_lap2d.restype = C.c_int
+        L.oracle_solve_lap2d_banded.argtypes = [C.c_int, C.c_int, C.c_double, C.c_int, dp, C.POINTER(OracleResult)]
+        L.oracle_solve_lap2d_banded.restype = C.c_int
         L.oracle_gemv.argtypes = [C.c_int, C.c_int, dp, C.c_long, dp, dp]
         L.oracle_gemv.restype = None
         L.oracle_dot.argtypes = [C.c_int, dp, dp]
@@ -142,6 +144,16 @@ def solve_lap2d(n, max_iter=None, tol=1e-10, psize=1):
     rc = lib().oracle_solve_lap2d(n, n if max_iter is None else max_iter, tol, psize, _dp(x), C.byref(res))
     if rc:
         raise RuntimeError("oracle_solve_lap2d failed: %d" % rc)
+    return x, res.as_dict()
+
+
+def solve_lap2d_banded(n, max_iter=None, tol=1e-10, psize=1):
+    """solve_lap2d with the generator's rule applied on the fly (no n x n block): checker for large n only."""
+    x = np.zeros(n, dtype=np.float64)
+    res = OracleResult()
+    rc = lib().oracle_solve_lap2d_banded(n, n if max_iter is None else max_iter, tol, psize, _dp(x), C.byref(res))
+    if rc:
+        raise RuntimeError("oracle_solve_lap2d_banded failed: %d" % rc)
     return x, res.as_dict()
 
 

@@ -193,3 +193,30 @@ def test_oracle_reader_matches_the_reference_reader(oracle, mtx_path, tmp_path):
         f = tmp_path / name
         f.write_text(text)
         assert np.array_equal(oracle.read_mtx_dense(str(f))[0], oracle.ref_read_mtx_dense(str(f))), name
+
+
+# ---- the on-the-fly twin used as checker for libcgx's opt-in banded storage at large n -------------------------
+@pytest.mark.parametrize("n,max_iter,p", [(2, None, 1), (3, None, 2), (100, None, 1), (1000, None, 3), (2048, 150, 4), (4096, 100, 1)])
+def test_banded_twin_matches_the_dense_oracle(oracle, n, max_iter, p):
+    """Same matrix (generator rule cg.cc:181-185), never materialised: must reproduce the dense restatement, which
+    is the one pinned to the reference.  Differences are summation-order noise of a 5-term row sum."""
+    xd, rd = oracle.solve_lap2d(n, max_iter, 1e-10, p)
+    xb, rb = oracle.solve_lap2d_banded(n, max_iter, 1e-10, p)
+    assert rd["iterations"] == rb["iterations"] and rd["converged"] == rb["converged"]
+    assert np.linalg.norm(xd - xb) <= 1e-13 * np.linalg.norm(xd)
+    if rd["residual_prev"] > 1e-6:
+        assert abs(rd["residual_prev"] - rb["residual_prev"]) <= 1e-9 * rd["residual_prev"]
+    assert abs(rd["x_norm"] - rb["x_norm"]) <= 1e-13 * rd["x_norm"]
+
+
+def test_banded_twin_at_the_pinned_large_sizes(oracle, reference_probe):
+    """N = 32768 / 500 iterations and N = 46340 / 200 iterations against the REFERENCE's recorded outputs
+    (tests/golden/reference_probe.json): the twin is pinned by the reference directly, not only through the dense port."""
+    for n, k in ((32768, 500), (46340, 200)):
+        row = [q for q in reference_probe["generated_large"] if q["n"] == n][0]
+        x, r = oracle.solve_lap2d_banded(n, k, 1e-10, 1)
+        assert r["iterations"] == row["k"] == k
+        assert abs(r["residual_prev"] - row["residual"]) <= 1e-6 * row["residual"]
+        assert abs(r["x_norm"] - row["x_norm"]) <= 1e-12 * row["x_norm"]
+        for i, v in row["x_samples"].items():
+            assert abs(x[int(i)] - v) <= 1e-12 * abs(v), i
