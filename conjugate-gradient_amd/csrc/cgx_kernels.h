@@ -112,7 +112,7 @@ struct DiaView {
     int ndiag;
     int off[kMaxDiags];
 };
-GemvPlan plan_dia(int rows);   // variant 3, grid = min(ceil(rows/256), 2048)
+GemvPlan plan_dia(int rows);   // variant 3, grid = min(ceil(rows/512), 2048)
 
 // K1 on banded storage: same contract as launch_gemv_plain / launch_gemv_fused (same iteration head, same p_new
 // = r + beta p_old, same one partial per workgroup), 8*(rows*ndiag) bytes of matrix instead of 8*rows*n.

@@ -664,7 +664,11 @@ __global__ __launch_bounds__(256) void k_update_xr_strided(int n, int rows, int 
 // one-partial-per-workgroup contract as the dense K1, so K3, the exchange and the host loop are shared.
 // Out-of-range columns are clamped instead of branched around: their stored value is exactly 0.
 // ------------------------------------------------------------------------------------------------
-template <int MODE>
+struct __attribute__((packed, aligned(8))) d2u {   // two consecutive doubles at an 8-B aligned address: one
+    double x, y;                                     // global_load_dwordx4 (unaligned access mode is on under HSA)
+};
+
+template <int MODE, int CH>
 __global__ __launch_bounds__(256) void k_spmv_dia(DiaView dv, int rows, int row0_global, int n, long lda,
                                                    const double *__restrict__ v, double *__restrict__ p_new, SegView sv,
                                                    double *__restrict__ Ap, double *__restrict__ partials, Scalars *sc,
@@ -679,26 +683,65 @@ __global__ __launch_bounds__(256) void k_spmv_dia(DiaView dv, int rows, int row0
         const IterHead h = iteration_head<4>(sc, sv, k, tol, lds);
         if (done || h.stop) return;
         beta = h.beta;
-        // p_new = r + beta p_old (cg.cc:127-129), stored once: the grid strides over all lda columns
-        for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < lda; c += (long)gridDim.x * 256)
-            p_new[c] = fma(beta, v[c], rfull[c]);
-    }
-    double d = 0.0;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < rows; i += (long)gridDim.x * 256) {
-        const long g = row0_global + i;
-        double acc = 0.0;
-#pragma unroll 4
-        for (int t = 0; t < dv.ndiag; ++t) {
-            long j = g + dv.off[t];
-            j = j < 0 ? 0 : (j > n - 1 ? n - 1 : j);
-            double pj = v[j];
-            if constexpr (FUSED) pj = fma(beta, pj, rfull[j]);   // same bits as the stored p_new[j]
-            acc = fma(dv.vals[t * dv.ld + i], pj, acc);          // cg.cc:100-102
+        // p_new = r + beta p_old (cg.cc:127-129) for the columns that are not rows of this shard (other ranks' rows
+        // and the pad); the shard's own rows are stored by the row loop below.
+        const long before = row0_global, after = lda - ((long)row0_global + rows);
+        for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < before + after; c += (long)gridDim.x * 256) {
+            const long cc = c < before ? c : c - before + row0_global + rows;
+            p_new[cc] = fma(beta, v[cc], rfull[cc]);
         }
-        Ap[i] = acc;
-        double pi = v[g];
-        if constexpr (FUSED) pi = fma(beta, pi, rfull[g]);
-        d = fma(pi, acc, d);                                     // cg.cc:105
+    }
+    // Two consecutive rows per thread, so that the diagonals (streamed once: non-temporal), the vectors, Ap and p_new
+    // all move as 16-B pieces.  Row i+1 needs no guard: behind the last row the diagonals hold zeros (ld is even and
+    // zero filled), the vectors are zero padded up to lda, and the Ap slice is padded to an even count.
+    // CH diagonals are in flight at a time: all their loads are issued before the first FMA (see K1 above).
+    double d = 0.0;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 2; i < rows; i += (long)gridDim.x * 512) {
+        const int g = row0_global + (int)i;
+        const d2u pv = *reinterpret_cast<const d2u *>(v + g);
+        d2u pr{0.0, 0.0};
+        if constexpr (FUSED) pr = *reinterpret_cast<const d2u *>(rfull + g);
+        double acc0 = 0.0, acc1 = 0.0;
+        for (int t0 = 0; t0 < dv.ndiag; t0 += CH) {
+            d2u qv[CH], qr[CH];
+            d2 a[CH];
+            bool low[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int t = t0 + u < dv.ndiag ? t0 + u : dv.ndiag - 1;   // tail of the last chunk: re-load, not used
+                const int j = g + dv.off[t];                              // column of row g; row g+1 has j+1
+                const int jb = j < 0 ? 0 : (j > n - 1 ? n - 1 : j);       // outside [0,n): the stored value is 0
+                low[u] = j < 0;                                           // j == -1: row g+1 needs column 0 = pair.x
+                qv[u] = *reinterpret_cast<const d2u *>(v + jb);
+                if constexpr (FUSED) qr[u] = *reinterpret_cast<const d2u *>(rfull + jb);
+                a[u] = load_a<true>(dv.vals + t * dv.ld + i);            // ld and i are even: 16-B aligned
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                if (t0 + u < dv.ndiag) {
+                    double q0 = qv[u].x, q1 = low[u] ? qv[u].x : qv[u].y;
+                    if constexpr (FUSED) {
+                        q0 = fma(beta, q0, qr[u].x);                      // same bits as the stored p_new[j]
+                        q1 = fma(beta, q1, low[u] ? qr[u].x : qr[u].y);
+                    }
+                    acc0 = fma(a[u].x, q0, acc0);                         // cg.cc:100-102
+                    acc1 = fma(a[u].y, q1, acc1);
+                }
+            }
+        }
+        double p0 = pv.x, p1 = pv.y;
+        if constexpr (FUSED) {
+            p0 = fma(beta, p0, pr.x);
+            p1 = fma(beta, p1, pr.y);
+            *reinterpret_cast<d2u *>(p_new + g) = d2u{p0, p1};            // column g+1 beyond the block: same value as
+        }                                                                 // the pre-pass stores (r is replicated)
+        d2 out;
+        out.x = acc0;
+        out.y = acc1;
+        *reinterpret_cast<d2 *>(Ap + i) = out;
+        d = fma(p0, acc0, d);                                             // cg.cc:105
+        d = fma(p1, acc1, d);                                             // row beyond the block: acc1 == 0
     }
     d = block_sum<4>(d, lds);
     if (threadIdx.x == 0) partials[blockIdx.x] = d;
@@ -1098,27 +1141,76 @@ GemvPlan plan_dia(int rows)
     pl.R = 1;
     pl.U = 1;
     pl.waves = 4;
-    pl.rows_per_wg = 256;
-    pl.grid = rows > 0 ? ceil_div(rows, 256) : 1;
-    if (pl.grid > 2048) pl.grid = 2048;   // above that the workgroups stride: K3 folds at most 2048 partials per rank
+    pl.rows_per_wg = 512;   // two consecutive rows per thread
+    pl.grid = rows > 0 ? ceil_div(rows, 512) : 1;
+    if (pl.grid > 2048) pl.grid = 2048;   // above that the workgroups stride: K3 folds at most 2048 partials per rank (1024..8192: same speed, measured)
     return pl;
 }
+
+namespace {
+
+struct DiaArgs {
+    DiaView dv;
+    int rows, row0, n;
+    long lda;
+    const double *v;
+    double *p_new;
+    SegView sv;
+    double *Ap, *partials;
+    Scalars *sc;
+    int k;
+    double tol;
+};
+
+template <int MODE, int CH>
+hipError_t launch_dia_chunk(const GemvPlan &pl, const DiaArgs &g, hipStream_t s)
+{
+    hipLaunchKernelGGL((k_spmv_dia<MODE, CH>), dim3(pl.grid), dim3(256), 0, s, g.dv, g.rows, g.row0, g.n, g.lda, g.v, g.p_new,
+                       g.sv, g.Ap, g.partials, g.sc, g.k, g.tol);
+    return hipGetLastError();
+}
+
+// Diagonals in flight per chunk: all of them up to 8; above that the chunk size in 5..8 that wastes the fewest
+// re-loads in the last chunk.
+int dia_chunk(int ndiag)
+{
+    if (ndiag <= 8) return ndiag < 1 ? 1 : ndiag;
+    int best = 8, waste = (8 - ndiag % 8) % 8;
+    for (int ch = 7; ch >= 5; --ch) {
+        const int w = (ch - ndiag % ch) % ch;
+        if (w < waste) { best = ch; waste = w; }
+    }
+    return best;
+}
+
+template <int MODE>
+hipError_t dispatch_dia(const GemvPlan &pl, const DiaArgs &g, hipStream_t s)
+{
+    switch (dia_chunk(g.dv.ndiag)) {
+    case 1: return launch_dia_chunk<MODE, 1>(pl, g, s);
+    case 2: return launch_dia_chunk<MODE, 2>(pl, g, s);
+    case 3: return launch_dia_chunk<MODE, 3>(pl, g, s);
+    case 4: return launch_dia_chunk<MODE, 4>(pl, g, s);
+    case 5: return launch_dia_chunk<MODE, 5>(pl, g, s);
+    case 6: return launch_dia_chunk<MODE, 6>(pl, g, s);
+    case 7: return launch_dia_chunk<MODE, 7>(pl, g, s);
+    default: return launch_dia_chunk<MODE, 8>(pl, g, s);
+    }
+}
+
+}  // namespace
 
 hipError_t launch_spmv_dia_plain(const GemvPlan &pl, const DiaView &dv, int rows, int row0, int n, const double *v_full,
                                  double *Ap, double *partials, Scalars *sc, hipStream_t s)
 {
-    hipLaunchKernelGGL((k_spmv_dia<kPlain>), dim3(pl.grid), dim3(256), 0, s, dv, rows, row0, n, 0L, v_full, nullptr,
-                       SegView{}, Ap, partials, sc, 0, 0.0);
-    return hipGetLastError();
+    return dispatch_dia<kPlain>(pl, DiaArgs{dv, rows, row0, n, 0L, v_full, nullptr, SegView{}, Ap, partials, sc, 0, 0.0}, s);
 }
 
 hipError_t launch_spmv_dia_fused(const GemvPlan &pl, const DiaView &dv, int rows, int row0, int n, long lda,
                                  const double *p_old, double *p_new, SegView seg, double *Ap, double *partials,
                                  Scalars *sc, int k, double tol, hipStream_t s)
 {
-    hipLaunchKernelGGL((k_spmv_dia<kFusedSingle>), dim3(pl.grid), dim3(256), 0, s, dv, rows, row0, n, lda, p_old, p_new,
-                       seg, Ap, partials, sc, k, tol);
-    return hipGetLastError();
+    return dispatch_dia<kFusedSingle>(pl, DiaArgs{dv, rows, row0, n, lda, p_old, p_new, seg, Ap, partials, sc, k, tol}, s);
 }
 
 int lap2d_offsets(int size, int *off)
