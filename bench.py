@@ -6,7 +6,7 @@
         bench.py --gpus N --steps K --warmup W          # row-block over N GPUs (configs[3], strong scaling)
 
 A "step" is one body of the CG loop (code/MPI/cg.cc:96-137 of the reference): one A.p GEMV over this
-rank's row block, two dot products, the x/r/p updates and the three exchanges.  Inputs are synthetic and
+rank's row block, two dot products, the x/r/p updates and the exchanges (here: ONE per iteration).  Inputs are synthetic and
 HBM-resident before the timed region: A = generate_lap2d_matrix(N) built on the device, b = init_source_term(1/N).
 W warmup steps, then exactly K steps between barrier + torch.cuda.synchronize(); MAX over ranks; rank 0
 prints ONE JSON line.  value = K / t for the whole job (every rank advances the same K iterations).

@@ -161,7 +161,7 @@ __device__ __forceinline__ d2 make_p(const SegView &sv, double beta, d2 p_old, i
 // per step (16 B/lane, L2 hit) and reused from registers by all R rows: vector traffic = 1/R of the A
 // stream.  U steps are issued back to back: R*U independent 1 KiB loads in flight per wave.
 // Epilogue: shuffle wave reduction, LDS cross-wave combine in fixed wave order, Ap store, and the
-// fused p.Ap (cg.cc:105) reduced over the grid by the last-arriving workgroup.
+// fused p.Ap (cg.cc:105): one partial per workgroup, folded by K3 in a fixed order (no atomics).
 // FUSED: the vector is p_new = r + beta p_old, formed in registers from two L2-resident streams; the
 // workgroup whose turn it is (step index mod grid) also stores it, so p_new is written exactly once.
 // ------------------------------------------------------------------------------------------------

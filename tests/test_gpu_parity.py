@@ -393,15 +393,16 @@ def test_config5_weak_scaling_sizes(gpu_pkg, reference_probe, n, p):
     _check_against_reference(x, r, row)
 
 
-def test_beyond_int_indexing_n65536(gpu_pkg):
-    """N=65536: N*N = 2^32 elements, past the reference's `int` index (matrix.hh:17 overflows above N=46340).
-    32 GiB of A on one GPU; no CPU oracle at this size, so size-independent properties: exact row sums, and the
-    same solution from 1 and from 4 row blocks."""
-    n = 65536
+@pytest.mark.parametrize("n,shard_counts", [(65536, (1, 4)), (131072, (1,))])
+def test_beyond_int_indexing(gpu_pkg, oracle, n, shard_counts):
+    """N=65536: N*N = 2^32 elements, past the reference's `int` index (matrix.hh:17 overflows above N=46340), 32 GiB of A.
+    N=131072: 128 GiB of A on one GPU (sized for the 288 GB of an MI355X).  No dense CPU oracle can exist at these sizes:
+    exact row sums, the same solution from 1 and from 4 row blocks, and the oracle's on-the-fly twin (the same matrix
+    rule applied without storing the block; pinned to the dense oracle and to the reference in tests/test_oracle.py)."""
     inc = int(np.floor(np.sqrt(n)))
     xs = []
-    for mode, p in ((gpu_pkg.COMM_SELF, 1), (gpu_pkg.COMM_LOOPBACK, 4)):
-        with gpu_pkg.CGSolver(comm_mode=mode, nranks=p) as s:
+    for p in shard_counts:
+        with gpu_pkg.CGSolver(comm_mode=gpu_pkg.COMM_SELF if p == 1 else gpu_pkg.COMM_LOOPBACK, nranks=p) as s:
             s.generate_lap2d_matrix(n)
             if p == 1:
                 ones, _ = s.probe_gemv(np.ones(n))
@@ -412,8 +413,12 @@ def test_beyond_int_indexing_n65536(gpu_pkg):
             r = s.solve(x)
             assert r["iterations"] == 25 and np.isfinite(r["residual_prev"])
             xs.append((x, r))
-    assert np.linalg.norm(xs[0][0] - xs[1][0]) / np.linalg.norm(xs[0][0]) < 1e-13
-    assert rel(xs[0][1]["residual_prev"], xs[1][1]["residual_prev"]) < 1e-10
+    xo, ro = oracle.solve_lap2d_banded(n, 25, 1e-10, 1)
+    assert np.linalg.norm(xs[0][0] - xo) / np.linalg.norm(xo) < 1e-12
+    assert rel(xs[0][1]["residual_prev"], ro["residual_prev"]) < 1e-6 and rel(xs[0][1]["x_norm"], ro["x_norm"]) < 1e-12
+    for x, r in xs[1:]:
+        assert np.linalg.norm(xs[0][0] - x) / np.linalg.norm(xs[0][0]) < 1e-13
+        assert rel(xs[0][1]["residual_prev"], r["residual_prev"]) < 1e-10
 
 
 # ---- command line -------------------------------------------------------------------------------------------------
