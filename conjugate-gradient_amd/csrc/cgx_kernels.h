@@ -98,9 +98,16 @@ hipError_t launch_debug_norms(int count, const double *Ax, const double *b, cons
 // generate_lap2d_matrix (cg.cc:159-188) for rows [row0,row0+rows) straight into device memory; pad columns = 0.
 hipError_t launch_generate_lap2d(double *A, long lda, int size, int row0, int rows, hipStream_t s);
 
-// Matrix::read scatter (matrix.cc:12-21): A[(I[z]-row0)*lda + J[z]] = a[z] for entries already filtered to this shard.
-hipError_t launch_scatter_coo(double *A, long lda, int row0, const int *I, const int *J, const double *a, long nz,
-                              hipStream_t s);
+// Matrix::read (matrix.cc:12-21) on the device, for the WHOLE entry list of the file in file order (0-based I, J;
+// `sym`: entry z also assigns (J,I) right after (I,J), matrix.cc:18-20).  Entries outside rows [row0,row0+rows) are
+// skipped.  A later assignment to the same element overrides an earlier one exactly as the sequential loop does:
+// three passes -- claim (64-bit atomic max of the assignment's sequence number into the element's own storage),
+// resolve (which assignment holds the element), write (the holder stores its value) -- no sort, no host-side map.
+// The block must be zero-filled before.  dv == nullptr: dense block A (rows x lda); else banded storage.
+struct DiaView;
+hipError_t launch_coo_assign(double *A, long lda, const DiaView *dv, double *dia_vals, int n, int row0, int rows,
+                             const int *I, const int *J, const double *a, long nz, int sym, unsigned char *win /* 2*nz */,
+                             hipStream_t s);
 
 // ---- banded storage (opt-in, NOT the reference's dense contract: SURVEY.md section 8f.3) ------------------
 // The row block as its non-zero diagonals: vals[t*ld + i] = A(row0+i, row0+i+off[t]) for local row i, exactly 0
@@ -129,10 +136,6 @@ hipError_t launch_dia_mark(const double *A, long lda, int n, int row0, int rows,
 // dense row block -> banded storage for the offsets in dv
 hipError_t launch_dia_pack(const double *A, long lda, int n, int row0, int rows, double *vals, const DiaView &dv,
                            hipStream_t s);
-// Matrix::read scatter into banded storage: vals[D[z]*ld + I[z]-row0] = a[z]
-hipError_t launch_dia_scatter_coo(double *vals, long ld, int row0, const int *I, const int *D, const double *a, long nz,
-                                  hipStream_t s);
-
 // ---- direct peer exchange (CGX_COMM_P2P): a lean all-gather over IPC-mapped mailboxes ---------------------
 // Every rank owns one fine-grained mailbox; all ranks map all mailboxes.  Layout (identical on every rank):
 //   flags : [kP2pChannels][kMaxRanks] words, one 128-B line each   (flag[c][q] = last epoch rank q delivered on channel c)

@@ -607,14 +607,6 @@ __global__ __launch_bounds__(256) void k_generate_lap2d(double *__restrict__ A, 
     }
 }
 
-__global__ __launch_bounds__(256) void k_scatter_coo(double *__restrict__ A, long lda, int row0,
-                                                      const int *__restrict__ I, const int *__restrict__ J,
-                                                      const double *__restrict__ a, long nz)
-{
-    for (long z = (long)blockIdx.x * 256 + threadIdx.x; z < nz; z += (long)gridDim.x * 256)
-        A[(long)(I[z] - row0) * lda + J[z]] = a[z];    // matrix.cc:17 (duplicates resolved on the host)
-}
-
 __global__ void k_loopback_gather(double *const *gathered_ptrs, const Scalars *const *scalar_ptrs, int nshards)
 {
     const int t = threadIdx.x;
@@ -784,12 +776,48 @@ __global__ __launch_bounds__(256) void k_dia_pack(const double *__restrict__ A, 
     }
 }
 
-__global__ __launch_bounds__(256) void k_dia_scatter_coo(double *__restrict__ vals, long ld, int row0,
-                                                          const int *__restrict__ I, const int *__restrict__ D,
-                                                          const double *__restrict__ a, long nz)
+// Matrix::read on the device (see cgx_kernels.h, launch_coo_assign).  Element of assignment (i,j): its index in the
+// block's own storage, or -1 if the row is not local (or, banded, the diagonal is not stored: cannot happen for
+// offsets collected from the same entries).
+template <bool BANDED>
+__device__ __forceinline__ long coo_cell(long lda, const DiaView &dv, int n, int row0, int rows, int i, int j)
 {
-    for (long z = (long)blockIdx.x * 256 + threadIdx.x; z < nz; z += (long)gridDim.x * 256)
-        vals[(long)D[z] * ld + (I[z] - row0)] = a[z];    // matrix.cc:17 (duplicates resolved on the host)
+    const int li = i - row0;
+    if (li < 0 || li >= rows) return -1;
+    if constexpr (!BANDED) {
+        return (long)li * lda + j;
+    } else {
+        const int off = j - i;
+        int lo = 0, hi = dv.ndiag - 1;
+        while (lo < hi) {                       // offsets are ascending, at most 64
+            const int mid = (lo + hi) >> 1;
+            if (dv.off[mid] < off) lo = mid + 1;
+            else hi = mid;
+        }
+        if (dv.ndiag <= 0 || dv.off[lo] != off) return -1;
+        return (long)lo * dv.ld + li;
+    }
+}
+
+// PASS 0: claim, 1: resolve, 2: write.  Sequence of assignment (z, mirror) = 2z + mirror + 1 (0 = untouched).
+template <bool BANDED, int PASS>
+__global__ __launch_bounds__(256) void k_coo_assign(double *__restrict__ cells, long lda, DiaView dv, int n, int row0,
+                                                     int rows, const int *__restrict__ I, const int *__restrict__ J,
+                                                     const double *__restrict__ a, long nz, int sym,
+                                                     unsigned char *__restrict__ win)
+{
+    unsigned long long *bits = reinterpret_cast<unsigned long long *>(cells);
+    for (long z = (long)blockIdx.x * 256 + threadIdx.x; z < nz; z += (long)gridDim.x * 256) {
+        const int i0 = I[z], j0 = J[z];
+        for (int mir = 0; mir <= (sym ? 1 : 0); ++mir) {
+            const long c = coo_cell<BANDED>(lda, dv, n, row0, rows, mir ? j0 : i0, mir ? i0 : j0);
+            if (c < 0) continue;
+            const unsigned long long seq = 2ull * (unsigned long long)z + mir + 1;
+            if constexpr (PASS == 0) atomicMax(bits + c, seq);                       // matrix.cc:17-20, last one wins
+            else if constexpr (PASS == 1) win[2 * z + mir] = bits[c] == seq;
+            else if (win[2 * z + mir]) cells[c] = a[z];
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1254,14 +1282,6 @@ hipError_t launch_dia_pack(const double *A, long lda, int n, int row0, int rows,
     return hipGetLastError();
 }
 
-hipError_t launch_dia_scatter_coo(double *vals, long ld, int row0, const int *I, const int *D, const double *a, long nz,
-                                  hipStream_t s)
-{
-    if (nz <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_dia_scatter_coo, dim3(capped_grid(nz, 2048)), dim3(256), 0, s, vals, ld, row0, I, D, a, nz);
-    return hipGetLastError();
-}
-
 hipError_t launch_update_xr_p2p(int n, int rows, int row0, const double *p_new, SegView apv, int npart,
                                 const MailboxView &mv, int chan, unsigned long long epoch, double *x, SegView rv, Scalars *sc,
                                 int parity, long long timeout_ticks, int *err, hipStream_t s)
@@ -1320,12 +1340,20 @@ hipError_t launch_generate_lap2d(double *A, long lda, int size, int row0, int ro
     return hipGetLastError();
 }
 
-hipError_t launch_scatter_coo(double *A, long lda, int row0, const int *I, const int *J, const double *a, long nz,
-                              hipStream_t s)
+hipError_t launch_coo_assign(double *A, long lda, const DiaView *dv, double *dia_vals, int n, int row0, int rows,
+                             const int *I, const int *J, const double *a, long nz, int sym, unsigned char *win, hipStream_t s)
 {
-    if (nz <= 0) return hipSuccess;
-    int grid = (int)((nz + 255) / 256 < 2048 ? (nz + 255) / 256 : 2048);
-    hipLaunchKernelGGL(k_scatter_coo, dim3(grid), dim3(256), 0, s, A, lda, row0, I, J, a, nz);
+    if (nz <= 0 || rows <= 0) return hipSuccess;
+    const int grid = capped_grid(nz, 4096);
+    if (dv) {
+        hipLaunchKernelGGL((k_coo_assign<true, 0>), dim3(grid), dim3(256), 0, s, dia_vals, 0L, *dv, n, row0, rows, I, J, a, nz, sym, win);
+        hipLaunchKernelGGL((k_coo_assign<true, 1>), dim3(grid), dim3(256), 0, s, dia_vals, 0L, *dv, n, row0, rows, I, J, a, nz, sym, win);
+        hipLaunchKernelGGL((k_coo_assign<true, 2>), dim3(grid), dim3(256), 0, s, dia_vals, 0L, *dv, n, row0, rows, I, J, a, nz, sym, win);
+    } else {
+        hipLaunchKernelGGL((k_coo_assign<false, 0>), dim3(grid), dim3(256), 0, s, A, lda, DiaView{}, n, row0, rows, I, J, a, nz, sym, win);
+        hipLaunchKernelGGL((k_coo_assign<false, 1>), dim3(grid), dim3(256), 0, s, A, lda, DiaView{}, n, row0, rows, I, J, a, nz, sym, win);
+        hipLaunchKernelGGL((k_coo_assign<false, 2>), dim3(grid), dim3(256), 0, s, A, lda, DiaView{}, n, row0, rows, I, J, a, nz, sym, win);
+    }
     return hipGetLastError();
 }
 

@@ -23,7 +23,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
-#include <unordered_map>
 #include <vector>
 
 #include "cgx_kernels.h"
@@ -920,75 +919,99 @@ cgx_status cgx_read_matrix(cgx_ctx *ctx, const char *path)
         return fail(ctx, CGX_ERR_UNSUPPORTED, "CG needs a square matrix with positive size");
     CGX_TRY(setup_problem(ctx, n));
 
-    // Keep only the entries (and mirrored entries) that land in a local row block; a later entry for the
-    // same (i,j) overrides an earlier one, as the sequential assignment in matrix.cc:12-21 does.
-    struct Coo {
-        std::vector<int> I, J;
-        std::vector<double> a;
-        std::unordered_map<unsigned long long, size_t> pos;
+    // The entries are parsed from large reads of the file (strtol/strtod on a buffer: the "%d %d %lg" of
+    // matrix_coo.cc:48 without a libc call per field) and kept in file order; everything after that -- which row
+    // block an entry belongs to, the mirrored assignment of a symmetric file, and "a later entry for the same (i,j)
+    // overrides an earlier one" (the sequential loop of matrix.cc:12-21) -- is done on the device.
+    std::vector<int> hI, hJ;
+    std::vector<double> ha;
+    hI.reserve((size_t)nz);
+    hJ.reserve((size_t)nz);
+    ha.reserve((size_t)nz);
+    std::vector<int> offs;   // banded: distinct (column - row) of all assignments, at most CGX_MAX_DIAGONALS + 1 kept
+    auto note_offset = [&](int off) {
+        if (!ctx->banded || (int)offs.size() > CGX_MAX_DIAGONALS) return;
+        auto it = std::lower_bound(offs.begin(), offs.end(), off);
+        if (it == offs.end() || *it != off) offs.insert(it, off);
     };
-    std::vector<Coo> coo(ctx->shards.size());
-    auto put = [&](int i, int j, double v) {
-        for (size_t si = 0; si < ctx->shards.size(); ++si) {
-            const Shard &s = ctx->shards[si];
-            if (i < s.row0 || i >= s.row0 + s.rows) continue;
-            Coo &c = coo[si];
-            const unsigned long long key = (unsigned long long)(unsigned)i << 32 | (unsigned)j;
-            auto it = c.pos.find(key);
-            if (it != c.pos.end()) c.a[it->second] = v;
-            else {
-                c.pos.emplace(key, c.a.size());
-                c.I.push_back(i);
-                c.J.push_back(j);
-                c.a.push_back(v);
+    {
+        const size_t kChunk = (size_t)32 << 20;
+        std::vector<char> buf(kChunk + 4096);
+        size_t have = 0;            // bytes of an unfinished token carried over from the previous read
+        int field = 0, I = 0, J = 0;
+        bool eof = false;
+        while ((long)ha.size() < (long)nz && !(eof && have == 0)) {
+            if (have + kChunk + 1 > buf.size()) buf.resize(have + kChunk + 1);
+            const size_t got = eof ? 0 : fread(buf.data() + have, 1, kChunk, f);
+            if (got < kChunk) eof = true;
+            size_t len = have + got, cut = len;
+            if (!eof) {             // stop at the last white space so that no token is split
+                while (cut > 0 && !isspace((unsigned char)buf[cut - 1])) --cut;
+                if (cut == 0) return fail(ctx, CGX_ERR_IO, "Matrix Market entry " + std::to_string(ha.size()) + " unreadable");
             }
+            const char saved = buf[cut];
+            buf[cut] = '\0';
+            char *p = buf.data();
+            while ((long)ha.size() < (long)nz) {
+                while (*p && isspace((unsigned char)*p)) ++p;
+                if (!*p) break;
+                char *e = p;
+                if (field < 2) {
+                    const long v = strtol(p, &e, 10);
+                    if (e == p) return fail(ctx, CGX_ERR_IO, "Matrix Market entry " + std::to_string(ha.size()) + " unreadable");
+                    (field == 0 ? I : J) = (int)v;
+                    ++field;
+                } else {
+                    const double a = strtod(p, &e);
+                    if (e == p) return fail(ctx, CGX_ERR_IO, "Matrix Market entry " + std::to_string(ha.size()) + " unreadable");
+                    field = 0;
+                    I--; J--;                                                             // matrix_coo.cc:49-50
+                    if (I < 0 || I >= m || J < 0 || J >= n) return fail(ctx, CGX_ERR_IO, "Matrix Market index out of range");
+                    hI.push_back(I);
+                    hJ.push_back(J);
+                    ha.push_back(a);
+                    note_offset(J - I);                                                   // matrix.cc:17
+                    if (is_sym) note_offset(I - J);                                       // matrix.cc:18-20
+                }
+                p = e;
+            }
+            buf[cut] = saved;
+            have = len - cut;
+            memmove(buf.data(), buf.data() + cut, have);
+            if (eof && (long)ha.size() < (long)nz && have == 0) break;
         }
-    };
-    for (int z = 0; z < nz; ++z) {
-        int I, J;
-        double a;
-        if (fscanf(f, "%d %d %lg", &I, &J, &a) != 3)
-            return fail(ctx, CGX_ERR_IO, "Matrix Market entry " + std::to_string(z) + " unreadable");
-        I--; J--;                                                                     // matrix_coo.cc:49-50
-        if (I < 0 || I >= m || J < 0 || J >= n) return fail(ctx, CGX_ERR_IO, "Matrix Market index out of range");
-        put(I, J, a);                                                                 // matrix.cc:17
-        if (is_sym) put(J, I, a);                                                     // matrix.cc:18-20
+        if ((long)ha.size() < (long)nz)
+            return fail(ctx, CGX_ERR_IO, "Matrix Market entry " + std::to_string(ha.size()) + " unreadable");
     }
-    for (size_t si = 0; si < ctx->shards.size(); ++si) {
-        Shard &s = ctx->shards[si];
-        Coo &c = coo[si];
-        if (ctx->banded) {
-            // the distinct (column - row) offsets of the stored entries are the diagonals; the scatter then takes
-            // the diagonal index in place of the column
-            std::vector<int> offs(c.J.size());
-            for (size_t z = 0; z < c.J.size(); ++z) offs[z] = c.J[z] - c.I[z];
-            std::sort(offs.begin(), offs.end());
-            offs.erase(std::unique(offs.begin(), offs.end()), offs.end());
-            CGX_TRY(alloc_dia(ctx, s, offs));
-            for (size_t z = 0; z < c.J.size(); ++z)
-                c.J[z] = (int)(std::lower_bound(offs.begin(), offs.end(), c.J[z] - c.I[z]) - offs.begin());
-        }
+    if (ctx->banded && (int)offs.size() > CGX_MAX_DIAGONALS)
+        return fail(ctx, CGX_ERR_UNSUPPORTED, "matrix has more than " + std::to_string(CGX_MAX_DIAGONALS) +
+                                                  " non-zero diagonals: not a banded matrix (use CGX_MATRIX_DENSE)");
+
+    const size_t cnt = ha.size();
+    struct DevBuf {
+        void *p = nullptr;
+        ~DevBuf() { (void)hipFree(p); }
+    } dI, dJ, da, dwin;
+    if (cnt) {
+        HIP_TRY(ctx, hipMalloc(&dI.p, cnt * sizeof(int)));
+        HIP_TRY(ctx, hipMalloc(&dJ.p, cnt * sizeof(int)));
+        HIP_TRY(ctx, hipMalloc(&da.p, cnt * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&dwin.p, 2 * cnt));
+        HIP_TRY(ctx, hipMemcpyAsync(dI.p, hI.data(), cnt * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(dJ.p, hJ.data(), cnt * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(da.p, ha.data(), cnt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    }
+    for (auto &s : ctx->shards) {
+        if (ctx->banded) CGX_TRY(alloc_dia(ctx, s, offs));   // zero-filled; every shard keeps the matrix's diagonals
         if (s.rows <= 0) continue;
         if (!ctx->banded)
             HIP_TRY(ctx, hipMemsetAsync(s.A, 0, (size_t)s.rows * ctx->lda * sizeof(double), ctx->stream));  // Matrix::resize zero-fills
-        const size_t cnt = c.a.size();
         if (!cnt) continue;
-        int *dI = nullptr, *dJ = nullptr;
-        double *da = nullptr;
-        HIP_TRY(ctx, hipMalloc(&dI, cnt * sizeof(int)));
-        HIP_TRY(ctx, hipMalloc(&dJ, cnt * sizeof(int)));
-        HIP_TRY(ctx, hipMalloc(&da, cnt * sizeof(double)));
-        HIP_TRY(ctx, hipMemcpyAsync(dI, c.I.data(), cnt * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(dJ, c.J.data(), cnt * sizeof(int), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(da, c.a.data(), cnt * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
-        if (ctx->banded)
-            HIP_TRY(ctx, cgx::launch_dia_scatter_coo(s.dia_vals, s.dia.ld, s.row0, dI, dJ, da, (long)cnt, ctx->stream));
-        else
-            HIP_TRY(ctx, cgx::launch_scatter_coo(s.A, ctx->lda, s.row0, dI, dJ, da, (long)cnt, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-        (void)hipFree(dI);
-        (void)hipFree(dJ);
-        (void)hipFree(da);
+        HIP_TRY(ctx, hipMemsetAsync(dwin.p, 0, 2 * cnt, ctx->stream));
+        HIP_TRY(ctx, cgx::launch_coo_assign(s.A, ctx->lda, ctx->banded ? &s.dia : nullptr, s.dia_vals, n, s.row0, s.rows,
+                                            static_cast<const int *>(dI.p), static_cast<const int *>(dJ.p),
+                                            static_cast<const double *>(da.p), (long)cnt, is_sym ? 1 : 0,
+                                            static_cast<unsigned char *>(dwin.p), ctx->stream));
     }
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->have_matrix = true;

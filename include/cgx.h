@@ -134,7 +134,8 @@ cgx_status  cgx_generate_lap2d_matrix(cgx_ctx *ctx, int size);
 cgx_status  cgx_set_matrix_dense(cgx_ctx *ctx, const double *A, long lda, int n);
 /* MatrixCOO::read + Matrix::read (matrix_coo.cc:7-60, matrix.cc:6-22) done by the library:
  * Matrix-Market `matrix coordinate {real,integer,double} {general,symmetric}` -> device row block,
- * without a dense n*n host staging copy. */
+ * without a dense n*n host staging copy.  Entries are assigned on the device in the file's order (a later
+ * entry for the same element wins, a symmetric entry's mirror follows it), exactly as the sequential loop. */
 cgx_status  cgx_read_matrix(cgx_ctx *ctx, const char *mtx_path);
 /* CGSolver::init_source_term(h), cg.cc:218-234: b evaluated on the HOST with libm sin so it is
  * bit-identical to the reference's, then this shard's slice is uploaded. */

@@ -337,6 +337,89 @@ def test_mtx_general_duplicates_and_errors(gpu_pkg, tmp_path):
             s.read_matrix(str(bad))
 
 
+def _sequential_model(n, entries, sym):
+    """Matrix::read as written in the reference (matrix.cc:12-21): assignments in file order."""
+    A = np.zeros((n, n))
+    for i, j, v in entries:
+        A[i, j] = v
+        if sym:
+            A[j, i] = v
+    return A
+
+
+@pytest.mark.parametrize("sym", [False, True])
+@pytest.mark.parametrize("fmt", ["dense", "banded"])
+def test_mtx_assignment_order_is_the_sequential_one(gpu_pkg, tmp_path, sym, fmt):
+    """Thousands of colliding assignments (same element hit many times, directly and through the mirror of a symmetric
+    file, explicit zeros, free-form white space): the device-side assignment must end with exactly the element values
+    of the reference's sequential loop, on 1 and on 3 row blocks."""
+    rng = np.random.default_rng(17 + sym)
+    n = 97
+    offs = np.array([-40, -3, -1, 0, 1, 2, 40])
+    entries = []
+    for _ in range(6000):
+        i = int(rng.integers(0, n))
+        j = i + int(rng.choice(offs))
+        if 0 <= j < n:
+            entries.append((i, j, float(rng.integers(-5, 6)) / 4.0))
+    seps = [" ", "  ", "\t", "\n", " \n "]
+    body = "".join("%d%s%d%s%r\n" % (i + 1, seps[k % 5], j + 1, seps[(k + 2) % 5], v) for k, (i, j, v) in enumerate(entries))
+    f = tmp_path / "collide.mtx"
+    f.write_text("%%%%MatrixMarket matrix coordinate real %s\n%% c\n%d %d %d\n" % ("symmetric" if sym else "general", n, n, len(entries)) + body)
+    want = _sequential_model(n, entries, sym)
+    for mode, p in ((gpu_pkg.COMM_SELF, 1), (gpu_pkg.COMM_LOOPBACK, 3)):
+        with gpu_pkg.CGSolver(comm_mode=mode, nranks=p,
+                              matrix_format=gpu_pkg.MATRIX_BANDED if fmt == "banded" else gpu_pkg.MATRIX_DENSE) as s:
+            s.read_matrix(str(f))
+            got = np.vstack([s.probe_matrix_rows(i)[0] for i in range(p)])
+        assert np.array_equal(got, want), (fmt, sym, p)
+
+
+def test_mtx_truncated_split_and_out_of_range(gpu_pkg, tmp_path):
+    with gpu_pkg.CGSolver() as s:
+        f = tmp_path / "t.mtx"
+        f.write_text("%%MatrixMarket matrix coordinate real general\n3 3 4\n1 1 2.5\n2 2 1\n3 3\n")          # entry 2 has no value
+        with pytest.raises(gpu_pkg.CgxError) as e:
+            s.read_matrix(str(f))
+        assert e.value.status == 2 and "entry 2" in str(e.value)
+        f.write_text("%%MatrixMarket matrix coordinate real general\n3 3 2\n1 1 2.5\n4 1 1\n")                 # row 4 of 3
+        with pytest.raises(gpu_pkg.CgxError) as e:
+            s.read_matrix(str(f))
+        assert e.value.status == 2 and "out of range" in str(e.value)
+        f.write_text("%%MatrixMarket matrix coordinate real general\n3 3 2\n1 1 x\n2 2 1\n")                   # not a number
+        with pytest.raises(gpu_pkg.CgxError) as e:
+            s.read_matrix(str(f))
+        assert e.value.status == 2
+        f.write_text("%%MatrixMarket matrix coordinate real general\n2 2 2\n1\n1\n3\n2 2\n-1e0 trailing text is ignored\n")
+        s.read_matrix(str(f))                                                                                   # like fscanf: any white space
+        assert np.array_equal(s.probe_matrix_rows(0)[0], np.array([[3.0, 0.0], [0.0, -1.0]]))
+
+
+def test_mtx_file_larger_than_one_read(gpu_pkg, tmp_path):
+    """A 50 MB file (the reader takes it in 32 MiB reads): 5-point Laplacian of a 1000 x 1000 grid, N = 10^6, banded
+    storage (no dense block of that size exists), checked through A.v against the stencil applied with numpy."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import make_lap2d_5pt
+    g = 1000
+    n = g * g
+    f = tmp_path / "lap_g1000.mtx"
+    f.write_text(make_lap2d_5pt.generate(g))
+    rng = np.random.default_rng(2)
+    v = rng.standard_normal(n)
+    with gpu_pkg.CGSolver(matrix_format=gpu_pkg.MATRIX_BANDED) as s:
+        s.read_matrix(str(f))
+        assert s.matrix_format(0)[1] == [-g, -1, 0, 1, g]
+        y, _ = s.probe_gemv(v)
+    V = v.reshape(g, g)
+    want = 4.0 * V
+    want[:, 1:] -= V[:, :-1]
+    want[:, :-1] -= V[:, 1:]
+    want[1:, :] -= V[:-1, :]
+    want[:-1, :] -= V[1:, :]
+    assert np.max(np.abs(y - want.ravel())) <= 1e-14 * np.max(np.abs(want))
+
+
 def test_mtx_solve_matches_reference_golden(gpu_pkg, mtx_path, reference_probe):
     """BASELINE.json configs[0] input on the GPU path, against the reference's recorded converged run."""
     row = reference_probe["mtx_lap2D_5pt_n100"][0]
