@@ -98,3 +98,36 @@ def test_product_package_never_touches_the_oracle():
                     if re.search(r"cg_oracle|oracle\.py|from oracle|import oracle|libcg_oracle|load_oracle", txt):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_header_is_plain_c_and_a_c_client_links(pkg, tmp_path):
+    """include/cgx.h is the boundary a C / cgo / JNI / ctypes client binds: it must compile as C99 with nothing but
+    itself, and a C program using only its host-side entry points must link against libcgx.so and run without a GPU."""
+    src = tmp_path / "client.c"
+    src.write_text(r'''
+#include "cgx.h"
+#include <stdio.h>
+#include <string.h>
+int main(void) {
+    int start[3], rows[3];
+    cgx_config cfg;
+    cgx_ctx *ctx = 0;
+    cgx_config_init(&cfg);
+    if (cfg.struct_version != CGX_VERSION || cfg.matrix_format != CGX_MATRIX_DENSE) return 2;
+    if (cgx_partition(10, 3, start, rows) != CGX_OK || rows[2] != 4) return 3;         /* cg.cc:255-266 */
+    cgx_status st = cgx_create(&ctx, &cfg);
+    if (st == CGX_OK) { cgx_destroy(ctx); printf("gpu\n"); return 0; }
+    if (st != CGX_ERR_NO_DEVICE || !strstr(cgx_last_error(0), "no CPU fallback")) return 4;
+    printf("%s\n", cgx_status_string(st));
+    return 0;
+}
+''')
+    exe = tmp_path / "client"
+    inc = os.path.join(ROOT, "include")
+    libdir = os.path.dirname(pkg.cgx.LIB_PATH)
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", inc, str(src), "-o", str(exe),
+                        "-L", libdir, "-lcgx", "-Wl,-rpath," + libdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
+    assert r.stdout.strip() in ("gpu", "no usable GPU (libcgx has no CPU fallback)")
