@@ -42,7 +42,7 @@ def parse_args():
                     help="multi-GPU exchange: direct xGMI mailboxes with the exchange folded into K3 (p2p) or as its own "
                          "kernel (p2p-sep), RCCL, or whichever of those works and calibrates fastest on this node (auto)")
     ap.add_argument("--lda-pad", type=int, default=-1)
-    ap.add_argument("--cpu-baseline-iters", type=int, default=10)
+    ap.add_argument("--cpu-baseline-iters", type=int, default=20)   # 20-50 loop bodies at N=32768, not 500
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-gemv", action="store_true", help="do not bracket K1 with HIP events")
     ap.add_argument("--profile-every", type=int, default=0,
@@ -88,6 +88,12 @@ def cpu_baseline(n, iters):
                   "%.1f s; %.1f s incl. building the 8*N^2-byte matrix)" % (n, iters, r["seconds_loop"], wall),
         "gemv_GBs": 8.0 * n * n * iters / r["seconds_loop"] / 1e9,
     }
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        model = "unknown"
+    out["host_cpu"] = model
+    out["host_cores_available"] = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     # context row: all host cores of this box's share, row blocks = threads = the
     # reference's MPI ranks; same arithmetic, bit-identical result
     try:
