@@ -1,0 +1,44 @@
+"""Randomised parity sweep (dev tool, not part of the suite): random size, row-block count, K1 shape and storage
+format; fixed number of iterations with tol = 0 on both sides; x, residual and ||x|| against the CPU oracle.
+python tools/fuzz_parity.py SECONDS [SEED]"""
+import os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import __graft_entry__ as g
+pkg = g.load_package(); O = g.load_oracle()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+VARIANTS = [0, 0, 0, 10821, 10811, 10441, 10421, 10241, 10281, 10181, 11611, 20821, 20441, 20241, 20181]
+t0 = time.time(); cases = 0; worst = 0.0
+while time.time() - t0 < budget:
+    n = int(rng.choice([rng.integers(1, 40), rng.integers(40, 700), rng.integers(700, 3000), rng.integers(3000, 6000)]))
+    P = int(rng.choice([1, 1, 2, 3, 4, 5, 7, 8, 11, 16]))
+    banded = bool(rng.integers(0, 2))
+    variant = 0 if banded else int(rng.choice(VARIANTS))
+    iters = int(rng.integers(1, 40))
+    iters = max(1, min(iters, n // 2))   # past ~n iterations the recurrence only moves rounding noise
+    every = int(rng.choice([0, 1, 3, 16]))
+    x0 = rng.standard_normal(n) if rng.integers(0, 2) else np.zeros(n)
+    A = O.generate_lap2d(n)
+    b = O.init_source_term(n)
+    if rng.integers(0, 3) == 0:
+        b = rng.standard_normal(n)
+    with pkg.CGSolver(comm_mode=pkg.COMM_LOOPBACK if P > 1 else pkg.COMM_SELF, nranks=P, gemv_variant=variant,
+                      check_every=every, matrix_format=pkg.MATRIX_BANDED if banded else pkg.MATRIX_DENSE) as s:
+        s.generate_lap2d_matrix(n); s.set_source_term(b); s.set_max_iter(iters); s.tolerance(0.0)
+        x = x0.copy(); r = s.solve(x)
+    xo, ro = O.solve(A, b, x0, iters, 0.0, P)
+    nx = np.linalg.norm(xo)
+    err = np.linalg.norm(x - xo) / nx if nx > 0 else np.linalg.norm(x - xo)
+    ok = r["iterations"] == ro["iterations"] == iters and (err < 1e-11 or not np.isfinite(nx))
+    if np.isfinite(ro["residual_prev"]) and ro["residual_prev"] > 1e-9 * np.linalg.norm(b):
+        ok = ok and abs(r["residual_prev"] - ro["residual_prev"]) <= 1e-6 * ro["residual_prev"]
+    worst = max(worst, err if np.isfinite(err) else 0.0)
+    cases += 1
+    if not ok:
+        print("MISMATCH n=%d P=%d banded=%d variant=%d iters=%d every=%d err=%.3e res %r vs %r" %
+              (n, P, banded, variant, iters, every, err, r["residual_prev"], ro["residual_prev"]), flush=True)
+        sys.exit(1)
+    if cases % 200 == 0:
+        print("%d cases ok, worst ||dx||/||x|| = %.2e, %.0f s" % (cases, worst, time.time() - t0), flush=True)
+print("done: %d cases ok, worst ||dx||/||x|| = %.2e" % (cases, worst))
