@@ -377,7 +377,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "generate_lap2d_matrix N=%d, init_source_term(1/N), fixed-iteration dense fp64 CG "
-                            "(BASELINE.json configs[%d])" % (n, 2 if world == 1 else (3 if args.mode == "strong" else 4)),
+                            "(BASELINE.json configs[%d])" % (n, 4 if args.mode == "weak" else (2 if world == 1 else 3)),
                 "n": n, "rows_per_gpu": rows0, "parallelism": "rowblock%d" % world,
                 "collectives": {"self": "none",
                                 "rccl": "1 x ncclAllGather per iteration ([Ap slice | p.Ap partials])",
