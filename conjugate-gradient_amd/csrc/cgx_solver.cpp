@@ -447,7 +447,8 @@ cgx_status run_gemv_plain(cgx_ctx *ctx, Shard &s, const double *v_full)
 cgx_status run_gemv_fused(cgx_ctx *ctx, Shard &s, int k)
 {
     const int every = ctx->cfg.profile_gemv;
-    const bool timed = every > 0 && (ctx->gemv_seq++ % every) == 0;
+    // at most 2048 timed launches per cgx_solve_steps call: the event pool stays bounded however long the run is
+    const bool timed = every > 0 && (ctx->gemv_seq++ % every) == 0 && ctx->ev_used + 2 <= 4096;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timed) {
         CGX_TRY(take_event(ctx, &e0));

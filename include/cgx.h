@@ -76,7 +76,7 @@ typedef struct cgx_config {
     int  gemv_variant;        /* 0 = library default; see DESIGN.md "K1 variants"           */
     int  lda_pad;             /* extra doubles added to the row pitch (-1 = library default)*/
     int  check_every;         /* iterations between host polls of the device `done` flag (0 = default) */
-    int  profile_gemv;        /* n > 0 = bracket every n-th K1 launch with HIP events       */
+    int  profile_gemv;        /* n > 0 = bracket every n-th K1 launch with HIP events (at most 2048 per cgx_solve_steps call) */
     int  reserved0;           /* (was: hipGraph replay; not needed, the host is never the bottleneck of this loop) */
     int  p2p_mailbox_kib;     /* CGX_COMM_P2P: mailbox size in KiB (0 = 4096)               */
     int  p2p_timeout_ms;      /* CGX_COMM_P2P: bound of every in-kernel wait (0 = 5000)     */
