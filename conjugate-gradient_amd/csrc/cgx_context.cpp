@@ -1,0 +1,481 @@
+// cgx_context.cpp -- life cycle of a libcgx context: configuration, device, stream, RCCL / mailbox wire-up, and
+// the allocation of the row-block shards (include/cgx.h "life cycle", "CGX_COMM_P2P wire-up", cgx_partition).
+#include "cgx_internal.h"
+
+#include <algorithm>
+#include <cctype>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace cgxi;
+
+namespace cgxi {
+
+thread_local std::string g_create_error;
+
+double wall_now()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+cgx_status fail(cgx_ctx *ctx, cgx_status st, const std::string &msg)
+{
+    if (ctx) ctx->err = msg;
+    else g_create_error = msg;
+    return st;
+}
+
+void partition_rows(int N, int psize, int *start_rows, int *num_rows)
+{
+    // CGSolver::partition_matrix, code/MPI/cg.cc:236-268: floor(N/psize) rows per rank, remainder on the last.
+    const int n_loc = (psize > 0) ? N / psize : N;
+    int i0 = 0;
+    for (int r = 0; r + 1 < psize; ++r) {
+        start_rows[r] = i0;
+        num_rows[r] = n_loc;
+        i0 += n_loc;
+    }
+    start_rows[psize - 1] = i0;
+    num_rows[psize - 1] = N - i0;
+}
+
+void free_shard(Shard &s)
+{
+    (void)hipFree(s.A);
+    (void)hipFree(s.dia_vals);
+    (void)hipFree(s.b_full);
+    (void)hipFree(s.x);
+    (void)hipFree(s.p[0]);
+    (void)hipFree(s.p[1]);
+    (void)hipFree(s.apg);
+    (void)hipFree(s.rbuf);
+    (void)hipFree(s.partials);
+    (void)hipFree(s.sc);
+    (void)hipFree(s.gathered);
+    s = Shard{};
+}
+
+void free_problem(cgx_ctx *ctx)
+{
+    for (auto &s : ctx->shards) free_shard(s);
+    ctx->shards.clear();
+    (void)hipFree(ctx->d_gathered_ptrs);
+    (void)hipFree(ctx->d_scalar_ptrs);
+    ctx->d_gathered_ptrs = nullptr;
+    ctx->d_scalar_ptrs = nullptr;
+    ctx->have_matrix = ctx->have_b = false;
+    ctx->in_solve = false;
+}
+
+// Mailbox bytes before the segment channel: flag words, channel 0 (16-B slots) and channel 2 (kSlots doubles).
+long p2p_fixed_prefix(int nranks)
+{
+    return (long)cgx::kP2pChannels * cgx::kMaxRanks * cgx::kP2pFlagStride + 2L * nranks * 16 +
+           2L * nranks * (long)cgx::kSlots * 8;
+}
+
+long default_lda(const cgx_ctx *ctx, int n)
+{
+    long lda = ((long)n + 15) / 16 * 16;   // every row starts on a 128-B line
+    int pad = ctx->cfg.lda_pad;
+    if (pad < 0) {
+        const char *e = getenv("CGX_LDA_PAD");
+        pad = e ? atoi(e) : 16;   // +128 B per row: de-aliases the HBM channels when N*8 is a power of two
+    }
+    if (pad > 0) lda += (pad + 1) / 2 * 2;
+    return lda;
+}
+
+// Allocate the shards for an n x n problem (matrix contents are filled by the caller).
+cgx_status setup_problem(cgx_ctx *ctx, int n)
+{
+    if (n <= 0) return fail(ctx, CGX_ERR_BAD_ARG, "matrix size must be positive");
+    if (n > (1 << 30)) return fail(ctx, CGX_ERR_UNSUPPORTED, "matrix size above 2^30 (indices are int, like the reference's)");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (!ctx->shards.empty() && ctx->n == n && ctx->lda == default_lda(ctx, n)) {
+        // Same geometry as the current problem: keep every buffer.  (Freeing and re-allocating a multi-GiB matrix
+        // can land on fragmented memory and cost ~3 % of K1; measured in bench.py's transport calibration.)
+        ctx->max_iter = n;
+        ctx->have_matrix = ctx->have_b = false;
+        ctx->in_solve = false;
+        for (auto &s : ctx->shards) {
+            HIP_TRY(ctx, hipMemsetAsync(s.p[0], 0, (size_t)ctx->lda * sizeof(double), ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(s.p[1], 0, (size_t)ctx->lda * sizeof(double), ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(s.sc, 0, sizeof(Scalars), ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(s.apg, 0, (size_t)ctx->nranks * ctx->seg_S * sizeof(double), ctx->stream));
+        }
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return CGX_OK;
+    }
+    free_problem(ctx);
+    ctx->m = ctx->n = n;
+    ctx->max_iter = n;   // m_maxIter = size, code/MPI/cg.cc:172
+    ctx->lda = default_lda(ctx, n);
+    ctx->start_rows.assign(ctx->nranks, 0);
+    ctx->num_rows.assign(ctx->nranks, 0);
+    partition_rows(n, ctx->nranks, ctx->start_rows.data(), ctx->num_rows.data());
+    int max_rows = 0;
+    for (int q = 0; q < ctx->nranks; ++q) max_rows = std::max(max_rows, ctx->num_rows[q]);
+    ctx->seg_Sr = std::max((max_rows + 1) / 2 * 2, 2);   // Ap slice, padded to an even count
+
+    int variant = ctx->cfg.gemv_variant;
+    if (variant <= 0) {
+        const char *e = getenv("CGX_GEMV_VARIANT");
+        if (e) variant = atoi(e);
+    }
+    auto plan_for = [&](int rows) { return ctx->banded ? cgx::plan_dia(rows) : cgx::plan_gemv(variant, rows, (int)ctx->lda); };
+    ctx->npart = 1;
+    for (int q = 0; q < ctx->nranks; ++q) ctx->npart = std::max(ctx->npart, plan_for(ctx->num_rows[q]).grid);
+    if (ctx->cfg.comm_mode == CGX_COMM_P2P && n > 256 * cgx::kMaxVectorGrid)
+        return fail(ctx, CGX_ERR_UNSUPPORTED, "CGX_COMM_P2P handles at most 262144 rows (the update kernel with the exchange "
+                                              "inside works one row per thread); use CGX_COMM_RCCL");
+    if (ctx->cfg.comm_mode == CGX_COMM_P2P) {
+        // mailbox layout of this problem: flags, then per channel [2 parities][nranks] slots
+        // The small fixed-size channels come first, so that their place never depends on the problem; the
+        // segment channel (1), whose slot size does, comes last.  A re-layout for a new problem size is then
+        // safe without a launcher barrier: the last exchange of a solve is on channel 2, and a rank can finish
+        // it only after every peer has pushed its channel-2 data, i.e. after every peer is done with channel 1.
+        const long slot[cgx::kP2pChannels] = {16, ((long)(ctx->seg_Sr + 1) * 8 + 15) / 16 * 16, (long)cgx::kSlots * 8};
+        long off = p2p_fixed_prefix(ctx->nranks);
+        ctx->mv.data_off[0] = (long)cgx::kP2pChannels * cgx::kMaxRanks * cgx::kP2pFlagStride;
+        ctx->mv.slot_bytes[0] = slot[0];
+        ctx->mv.data_off[2] = ctx->mv.data_off[0] + 2L * ctx->nranks * slot[0];
+        ctx->mv.slot_bytes[2] = slot[2];
+        ctx->mv.data_off[1] = off;
+        ctx->mv.slot_bytes[1] = slot[1];
+        off += 2L * ctx->nranks * slot[1];
+        if ((size_t)off > ctx->mailbox_bytes)
+            return fail(ctx, CGX_ERR_P2P, "mailbox too small for this problem: need " + std::to_string(off) +
+                                              " bytes (raise cgx_config.p2p_mailbox_kib)");
+    }
+    const int seg_tail = (ctx->npart + 1 + 1) / 2 * 2;   // npart partials + 1 slot for a rank's folded sum, even
+    ctx->seg_S = ctx->seg_Sr + seg_tail;
+    const int nlocal = (ctx->cfg.comm_mode == CGX_COMM_LOOPBACK) ? ctx->nranks : 1;
+    ctx->shards.resize(nlocal);
+    for (int i = 0; i < nlocal; ++i) {
+        Shard &s = ctx->shards[i];
+        s.rank = (ctx->cfg.comm_mode == CGX_COMM_RCCL || ctx->cfg.comm_mode == CGX_COMM_P2P) ? ctx->cfg.rank : i;
+        s.row0 = ctx->start_rows[s.rank];
+        s.rows = ctx->num_rows[s.rank];
+        s.plan = plan_for(s.rows);
+        const size_t rows_alloc = (size_t)std::max(s.rows, 1);
+        s.npartials = 3 * cgx::update_xr_grid(n) + 8;
+        if (!ctx->banded) HIP_TRY(ctx, hipMalloc(&s.A, rows_alloc * (size_t)ctx->lda * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&s.b_full, (size_t)n * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&s.x, rows_alloc * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&s.p[0], (size_t)ctx->lda * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&s.p[1], (size_t)ctx->lda * sizeof(double)));
+        const size_t apg_bytes = (size_t)ctx->nranks * ctx->seg_S * sizeof(double);
+        const int rr_parts = cgx::update_xr_grid(n);   // one r.r partial per K3 workgroup
+        const size_t rbuf_bytes = (size_t)(ctx->lda + rr_parts) * sizeof(double);
+        HIP_TRY(ctx, hipMalloc(&s.apg, apg_bytes));
+        HIP_TRY(ctx, hipMalloc(&s.rbuf, rbuf_bytes));
+        s.apv = cgx::SegView{s.apg, ctx->seg_S, ctx->seg_Sr, n / ctx->nranks, ctx->nranks, n, s.rank, 0, 0, 0};
+        cgx::seg_finalize(&s.apv);
+        s.rv = cgx::SegView{s.rbuf, (int)ctx->lda + rr_parts, (int)ctx->lda, n, 1, n, 0, 0, 0, 0};
+        cgx::seg_finalize(&s.rv);
+        HIP_TRY(ctx, hipMalloc(&s.partials, (size_t)s.npartials * sizeof(double)));
+        HIP_TRY(ctx, hipMalloc(&s.sc, sizeof(Scalars)));
+        HIP_TRY(ctx, hipMalloc(&s.gathered, (size_t)cgx::kMaxRanks * cgx::kSlots * sizeof(double)));
+        HIP_TRY(ctx, hipMemsetAsync(s.p[0], 0, (size_t)ctx->lda * sizeof(double), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(s.p[1], 0, (size_t)ctx->lda * sizeof(double), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(s.apg, 0, apg_bytes, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(s.rbuf, 0, rbuf_bytes, ctx->stream));
+        if (s.rows <= 0 && s.A) HIP_TRY(ctx, hipMemsetAsync(s.A, 0, (size_t)ctx->lda * sizeof(double), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(s.partials, 0, (size_t)s.npartials * sizeof(double), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(s.sc, 0, sizeof(Scalars), ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(s.gathered, 0, (size_t)cgx::kMaxRanks * cgx::kSlots * sizeof(double), ctx->stream));
+    }
+    if (ctx->cfg.comm_mode == CGX_COMM_LOOPBACK) {
+        std::vector<double *> gp(nlocal);
+        std::vector<Scalars *> sp(nlocal);
+        for (int i = 0; i < nlocal; ++i) {
+            gp[i] = ctx->shards[i].gathered;
+            sp[i] = ctx->shards[i].sc;
+        }
+        HIP_TRY(ctx, hipMalloc(&ctx->d_gathered_ptrs, nlocal * sizeof(double *)));
+        HIP_TRY(ctx, hipMalloc(&ctx->d_scalar_ptrs, nlocal * sizeof(Scalars *)));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_gathered_ptrs, gp.data(), nlocal * sizeof(double *), hipMemcpyHostToDevice));
+        HIP_TRY(ctx, hipMemcpy(ctx->d_scalar_ptrs, sp.data(), nlocal * sizeof(Scalars *), hipMemcpyHostToDevice));
+    }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return CGX_OK;
+}
+
+}  // namespace cgxi
+
+extern "C" {
+
+void cgx_config_init(cgx_config *cfg)
+{
+    if (!cfg) return;
+    memset(cfg, 0, sizeof *cfg);
+    cfg->struct_version = CGX_VERSION;
+    cfg->comm_mode = CGX_COMM_SELF;
+    cfg->device = 0;
+    cfg->rank = 0;
+    cfg->nranks = 1;
+    cfg->lda_pad = -1;
+}
+
+const char *cgx_status_string(cgx_status s)
+{
+    switch (s) {
+    case CGX_OK: return "ok";
+    case CGX_ERR_BAD_ARG: return "bad argument";
+    case CGX_ERR_IO: return "i/o error";
+    case CGX_ERR_HIP: return "HIP error";
+    case CGX_ERR_RCCL: return "RCCL error";
+    case CGX_ERR_OOM: return "out of memory";
+    case CGX_ERR_NO_DEVICE: return "no usable GPU (libcgx has no CPU fallback)";
+    case CGX_ERR_UNSUPPORTED: return "unsupported input";
+    case CGX_ERR_P2P: return "direct peer exchange failed";
+    }
+    return "unknown";
+}
+
+const char *cgx_last_error(const cgx_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+cgx_status cgx_partition(int n, int psize, int *start_rows, int *num_rows)
+{
+    if (n < 0 || psize <= 0 || !start_rows || !num_rows) return CGX_ERR_BAD_ARG;
+    partition_rows(n, psize, start_rows, num_rows);
+    return CGX_OK;
+}
+
+cgx_status cgx_comm_unique_id(unsigned char out[CGX_UNIQUE_ID_BYTES])
+{
+    static_assert(sizeof(ncclUniqueId) == CGX_UNIQUE_ID_BYTES, "ncclUniqueId size");
+    if (!out) return CGX_ERR_BAD_ARG;
+    std::string err;
+    const cgx::RcclApi *api = cgx::rccl_api(&err);
+    if (!api) return fail(nullptr, CGX_ERR_RCCL, err);
+    ncclUniqueId id;
+    ncclResult_t r = api->GetUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, CGX_ERR_RCCL, std::string("ncclGetUniqueId: ") + api->GetErrorString(r));
+    memcpy(out, &id, CGX_UNIQUE_ID_BYTES);
+    return CGX_OK;
+}
+
+cgx_status cgx_create(cgx_ctx **out, const cgx_config *cfg_in)
+{
+    if (!out) return fail(nullptr, CGX_ERR_BAD_ARG, "cgx_create: out is null");
+    *out = nullptr;
+    cgx_config cfg;
+    if (cfg_in) cfg = *cfg_in;
+    else cgx_config_init(&cfg);
+    if (cfg.struct_version != CGX_VERSION) return fail(nullptr, CGX_ERR_BAD_ARG, "cgx_config.struct_version mismatch");
+    if (cfg.nranks <= 0) cfg.nranks = 1;
+    if (cfg.comm_mode == CGX_COMM_SELF && cfg.nranks != 1)
+        return fail(nullptr, CGX_ERR_BAD_ARG, "CGX_COMM_SELF requires nranks == 1");
+    if (cfg.comm_mode == CGX_COMM_LOOPBACK && cfg.nranks > 16)
+        return fail(nullptr, CGX_ERR_BAD_ARG, "CGX_COMM_LOOPBACK supports at most 16 logical shards");
+    if ((cfg.comm_mode == CGX_COMM_RCCL || cfg.comm_mode == CGX_COMM_P2P) &&
+        (cfg.rank < 0 || cfg.rank >= cfg.nranks || cfg.nranks > cgx::kMaxRanks))
+        return fail(nullptr, CGX_ERR_BAD_ARG, "CGX_COMM_RCCL/P2P: rank out of range or nranks > 64");
+    if (cfg.comm_mode < CGX_COMM_SELF || cfg.comm_mode > CGX_COMM_P2P)
+        return fail(nullptr, CGX_ERR_BAD_ARG, "unknown comm_mode");
+    if (cfg.matrix_format != CGX_MATRIX_DENSE && cfg.matrix_format != CGX_MATRIX_BANDED)
+        return fail(nullptr, CGX_ERR_BAD_ARG, "unknown matrix_format");
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, CGX_ERR_NO_DEVICE,
+                    std::string("no HIP device visible (") + hipGetErrorString(e) + "); libcgx has no CPU fallback");
+    if (cfg.device < 0 || cfg.device >= ndev) return fail(nullptr, CGX_ERR_NO_DEVICE, "device ordinal out of range");
+
+    cgx_ctx *ctx = new (std::nothrow) cgx_ctx();
+    if (!ctx) return fail(nullptr, CGX_ERR_OOM, "host allocation failed");
+    ctx->cfg = cfg;
+    ctx->device = cfg.device;
+    ctx->nranks = cfg.nranks;
+    ctx->banded = cfg.matrix_format == CGX_MATRIX_BANDED;
+    if (ctx->cfg.check_every <= 0) ctx->cfg.check_every = 16;
+    if (getenv("CGX_P2P_SEPARATE_EXCHANGE")) ctx->cfg.p2p_separate_exchange = 1;
+
+    auto bail = [&](cgx_status st) {
+        g_create_error = ctx->err;
+        cgx_destroy(ctx);
+        return st;
+    };
+    if (hipSetDevice(ctx->device) != hipSuccess) {
+        ctx->err = "hipSetDevice failed";
+        return bail(CGX_ERR_NO_DEVICE);
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) {
+        ctx->err = "hipGetDeviceProperties failed";
+        return bail(CGX_ERR_HIP);
+    }
+    if (!strstr(prop.gcnArchName, "gfx950") && !getenv("CGX_ALLOW_ANY_ARCH")) {
+        ctx->err = std::string("device is ") + prop.gcnArchName + ", libcgx is built for gfx950 (MI355X) only";
+        return bail(CGX_ERR_NO_DEVICE);
+    }
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        ctx->err = "hipStreamCreate failed";
+        return bail(CGX_ERR_HIP);
+    }
+    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_flags), 4 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->flag_ev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->flag_ev[1], hipEventDisableTiming) != hipSuccess) {
+        ctx->err = "pinned flag / event allocation failed";
+        return bail(CGX_ERR_HIP);
+    }
+    if (cfg.comm_mode == CGX_COMM_RCCL) {
+        std::string err;
+        ctx->rccl = cgx::rccl_api(&err);
+        if (!ctx->rccl) {
+            ctx->err = err;
+            return bail(CGX_ERR_RCCL);
+        }
+        ncclUniqueId id;
+        memcpy(&id, cfg.unique_id, CGX_UNIQUE_ID_BYTES);
+        ncclResult_t r = ctx->rccl->CommInitRank(&ctx->comm, cfg.nranks, id, cfg.rank);
+        if (r != ncclSuccess) {
+            ctx->err = std::string("ncclCommInitRank: ") + ctx->rccl->GetErrorString(r);
+            ctx->comm = nullptr;
+            return bail(CGX_ERR_RCCL);
+        }
+    }
+    if (cfg.comm_mode == CGX_COMM_P2P) {
+        ctx->mailbox_bytes = (size_t)(cfg.p2p_mailbox_kib > 0 ? cfg.p2p_mailbox_kib : 4096) * 1024;
+        ctx->p2p_timeout_ticks = (long long)(cfg.p2p_timeout_ms > 0 ? cfg.p2p_timeout_ms : 5000) * 100000LL;   // 100 MHz
+        // fine-grained: stores from peers and system-scope atomics are coherent without a kernel boundary
+        if (hipExtMallocWithFlags(reinterpret_cast<void **>(&ctx->mailbox), ctx->mailbox_bytes, hipDeviceMallocFinegrained) != hipSuccess ||
+            hipMemset(ctx->mailbox, 0, ctx->mailbox_bytes) != hipSuccess ||
+            hipMalloc(reinterpret_cast<void **>(&ctx->d_p2p_err), sizeof(int)) != hipSuccess ||
+            hipMemset(ctx->d_p2p_err, 0, sizeof(int)) != hipSuccess) {
+            ctx->err = "mailbox allocation failed";
+            return bail(CGX_ERR_P2P);
+        }
+        ctx->mv.nranks = cfg.nranks;
+        ctx->mv.rank = cfg.rank;
+        ctx->mv.base[cfg.rank] = ctx->mailbox;
+        if (cfg.nranks == 1) ctx->p2p_ready = true;
+    }
+    *out = ctx;
+    return CGX_OK;
+}
+
+cgx_status cgx_p2p_export(cgx_ctx *ctx, unsigned char out[CGX_IPC_HANDLE_BYTES])
+{
+    static_assert(sizeof(hipIpcMemHandle_t) == CGX_IPC_HANDLE_BYTES, "hipIpcMemHandle_t size");
+    if (!ctx || !out || ctx->cfg.comm_mode != CGX_COMM_P2P) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_p2p_export: not a P2P context");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipIpcMemHandle_t h;
+    HIP_TRY(ctx, hipIpcGetMemHandle(&h, ctx->mailbox));
+    memcpy(out, &h, CGX_IPC_HANDLE_BYTES);
+    return CGX_OK;
+}
+
+cgx_status cgx_p2p_import(cgx_ctx *ctx, const unsigned char *handles)
+{
+    if (!ctx || !handles || ctx->cfg.comm_mode != CGX_COMM_P2P) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_p2p_import: not a P2P context");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (int q = 0; q < ctx->nranks; ++q) {
+        if (q == ctx->cfg.rank) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, handles + (size_t)q * CGX_IPC_HANDLE_BYTES, CGX_IPC_HANDLE_BYTES);
+        void *ptr = nullptr;
+        hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess)
+            return fail(ctx, CGX_ERR_P2P, std::string("hipIpcOpenMemHandle(rank ") + std::to_string(q) + "): " + hipGetErrorString(e));
+        ctx->mv.base[q] = static_cast<unsigned char *>(ptr);
+    }
+    ctx->p2p_ready = true;
+    return CGX_OK;
+}
+
+cgx_status cgx_p2p_selftest(cgx_ctx *ctx, int rounds, int *ok)
+{
+    if (!ctx || !ok || rounds <= 0 || ctx->cfg.comm_mode != CGX_COMM_P2P) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_p2p_selftest: bad argument");
+    *ok = 0;
+    if (!ctx->p2p_ready) return fail(ctx, CGX_ERR_P2P, "cgx_p2p_import has not been called");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int P = ctx->nranks, me = ctx->cfg.rank;
+    const int count = 1024;   // doubles per rank: 8 KiB, the size class of the real exchanges
+    cgx::MailboxView saved = ctx->mv;
+    ctx->mv.data_off[1] = p2p_fixed_prefix(P);
+    ctx->mv.slot_bytes[1] = (long)count * 8;
+    if ((size_t)(ctx->mv.data_off[1] + 2L * P * count * 8) > ctx->mailbox_bytes) {
+        ctx->mv = saved;
+        return fail(ctx, CGX_ERR_P2P, "mailbox too small for the self-test");
+    }
+    double *dsrc = nullptr, *ddst = nullptr;
+    HIP_TRY(ctx, hipMalloc(&dsrc, (size_t)count * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc(&ddst, (size_t)P * count * sizeof(double)));
+    std::vector<double> hsrc(count), hdst((size_t)P * count);
+    bool good = true;
+    cgx_status st = CGX_OK;
+    for (int r = 0; r < rounds && good; ++r) {
+        for (int i = 0; i < count; ++i) hsrc[i] = 1e6 * (me + 1) + 1e3 * r + i + 0.25;
+        HIP_TRY(ctx, hipMemcpyAsync(dsrc, hsrc.data(), count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipMemsetAsync(ddst, 0, (size_t)P * count * sizeof(double), ctx->stream));
+        st = p2p_allgather(ctx, 1, dsrc, count, ddst, count, 1);
+        if (st != CGX_OK) break;
+        HIP_TRY(ctx, hipMemcpyAsync(hdst.data(), ddst, (size_t)P * count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (check_p2p_error(ctx) != CGX_OK) { good = false; break; }
+        for (int q = 0; q < P && good; ++q)
+            for (int i = 0; i < count; ++i)
+                if (hdst[(size_t)q * count + i] != 1e6 * (q + 1) + 1e3 * r + i + 0.25) { good = false; break; }
+    }
+    (void)hipFree(dsrc);
+    (void)hipFree(ddst);
+    ctx->mv = saved;
+    if (st != CGX_OK) return st;
+    *ok = good ? 1 : 0;
+    return CGX_OK;
+}
+
+cgx_status cgx_destroy(cgx_ctx *ctx)
+{
+    if (!ctx) return CGX_OK;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    free_problem(ctx);
+    if (ctx->comm && ctx->rccl) (void)ctx->rccl->CommDestroy(ctx->comm);
+    if (ctx->cfg.comm_mode == CGX_COMM_P2P) {
+        for (int q = 0; q < ctx->nranks; ++q)
+            if (q != ctx->cfg.rank && ctx->mv.base[q]) (void)hipIpcCloseMemHandle(ctx->mv.base[q]);
+        if (ctx->mailbox) (void)hipFree(ctx->mailbox);
+        if (ctx->d_p2p_err) (void)hipFree(ctx->d_p2p_err);
+    }
+    for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+    for (auto e : ctx->flag_ev)
+        if (e) (void)hipEventDestroy(e);
+    if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return CGX_OK;
+}
+
+cgx_status cgx_get_size(const cgx_ctx *ctx, int *m, int *n)
+{
+    if (!ctx) return CGX_ERR_BAD_ARG;
+    if (m) *m = ctx->m;
+    if (n) *n = ctx->n;
+    return CGX_OK;
+}
+
+cgx_status cgx_set_max_iter(cgx_ctx *ctx, int max_iter)
+{
+    if (!ctx) return CGX_ERR_BAD_ARG;
+    ctx->max_iter = max_iter;   // the reference does not validate either (cg.cc:204-216)
+    return CGX_OK;
+}
+
+cgx_status cgx_set_tolerance(cgx_ctx *ctx, double tol)
+{
+    if (!ctx) return CGX_ERR_BAD_ARG;
+    ctx->tol = tol;
+    return CGX_OK;
+}
+
+}  // extern "C"

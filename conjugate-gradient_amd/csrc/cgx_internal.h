@@ -1,0 +1,147 @@
+// cgx_internal.h -- what the translation units of libcgx share: the context, the per-shard buffers, the error
+// macros and the internal helpers.  Nothing here is part of the C ABI (include/cgx.h).
+#pragma once
+
+#include "../../include/cgx.h"
+
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "cgx_kernels.h"
+#include "cgx_rccl.h"
+
+namespace cgxi {
+
+using cgx::Scalars;
+
+struct Shard {
+    int rank = 0;
+    int row0 = 0;
+    int rows = 0;
+    double *A = nullptr;         // rows x lda, row-major, pad columns zero (CGX_MATRIX_DENSE)
+    double *dia_vals = nullptr;  // CGX_MATRIX_BANDED: ndiag x dia.ld, the non-zero diagonals of the row block
+    cgx::DiaView dia{};
+    double *b_full = nullptr;    // n doubles: b is replicated like r (the reference builds the full b on every rank, cg.cc:218-234)
+    double *x = nullptr;         // rows
+    double *p[2] = {nullptr, nullptr};   // lda doubles each: the replicated p (cg.cc:57), ping-pong over iterations
+    double *apg = nullptr;       // nranks * S doubles: exchanged segments [Ap slice | p.Ap partials] (cgx::SegView apv)
+    double *rbuf = nullptr;      // lda + kSlots doubles: the replicated r and its scalars (cgx::SegView rv, one segment)
+    double *partials = nullptr;  // scratch: per-workgroup partial sums of K3 and of the setup kernels
+    Scalars *sc = nullptr;
+    double *gathered = nullptr;  // kMaxRanks * kSlots doubles (DEBUG scalars of all ranks)
+    cgx::GemvPlan plan{};
+    cgx::SegView apv{}, rv{};
+    int npartials = 0;
+    double *Ap() const { return apg + (size_t)rank * apv.S; }          // this shard's Ap slice (K1 output)
+    double *k1_part() const { return Ap() + apv.Sr; }                   // this shard's p.Ap partials (segment tail)
+};
+
+
+}  // namespace cgxi
+
+struct cgx_ctx {
+    cgx_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    int nranks = 1;
+    int m = 0, n = 0;
+    long lda = 0;
+    int max_iter = 0;
+    double tol = 1e-10;   // m_tolerance, code/MPI/cg.hh:56
+    std::vector<int> start_rows, num_rows;
+    std::vector<cgxi::Shard> shards;   // 1 (SELF / RCCL) or nranks (LOOPBACK)
+    std::vector<double> b_host;
+    bool have_matrix = false, have_b = false;
+    bool banded = false;         // cfg.matrix_format == CGX_MATRIX_BANDED (opt-in, not the reference's storage)
+
+    // RCCL
+    const cgx::RcclApi *rccl = nullptr;
+    ncclComm_t comm = nullptr;
+    // direct peer exchange (CGX_COMM_P2P)
+    unsigned char *mailbox = nullptr;        // own fine-grained mailbox
+    size_t mailbox_bytes = 0;
+    bool p2p_ready = false;                  // peers' mailboxes are mapped
+    cgx::MailboxView mv{};
+    unsigned long long p2p_epoch[cgx::kP2pChannels] = {0, 0, 0};
+    int *d_p2p_err = nullptr;                // device word set when a bounded wait expired
+    long long p2p_timeout_ticks = 0;         // 100 MHz wall-clock ticks
+
+    int seg_S = 0, seg_Sr = 0;   // exchange segment geometry (equal for all ranks)
+    int npart = 0;               // K1 partials per rank in exchange 1 (max grid over ranks)
+
+    // loopback pointer tables (device)
+    double **d_gathered_ptrs = nullptr;
+    cgx::Scalars **d_scalar_ptrs = nullptr;
+
+    // solve state
+    bool in_solve = false;
+    int k = 0;              // iterations enqueued so far
+    bool done = false;
+    int k_final = 0;
+    int *h_flags = nullptr;   // pinned: 2 slots x {done, k_final}
+    hipEvent_t flag_ev[2] = {nullptr, nullptr};
+    double t_begin = 0, t_loop = 0;
+
+    // K1 timing
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    double gemv_ms_sum = 0, gemv_ms_min = 0;
+    long long gemv_launches = 0;
+    long long gemv_seq = 0;
+
+    std::string err;
+};
+
+
+namespace cgxi {
+
+extern thread_local std::string g_create_error;   // error of the last failed cgx_create on this thread
+
+double wall_now();
+cgx_status fail(cgx_ctx *ctx, cgx_status st, const std::string &msg);
+
+#define HIP_TRY(ctx, call)                                                                              \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            cgx_status st_ = (e_ == hipErrorOutOfMemory) ? CGX_ERR_OOM                                  \
+                             : (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? CGX_ERR_NO_DEVICE \
+                                                                                       : CGX_ERR_HIP;   \
+            return fail(ctx, st_, std::string(#call) + ": " + hipGetErrorString(e_));                   \
+        }                                                                                               \
+    } while (0)
+
+#define NCCL_TRY(ctx, call)                                                                             \
+    do {                                                                                                \
+        ncclResult_t r_ = (call);                                                                       \
+        if (r_ != ncclSuccess)                                                                          \
+            return fail(ctx, CGX_ERR_RCCL, std::string(#call) + ": " + (ctx)->rccl->GetErrorString(r_)); \
+    } while (0)
+
+#define CGX_TRY(call)                      \
+    do {                                   \
+        cgx_status s_ = (call);            \
+        if (s_ != CGX_OK) return s_;       \
+    } while (0)
+
+
+// cgx_context.cpp
+void partition_rows(int N, int psize, int *start_rows, int *num_rows);
+void free_problem(cgx_ctx *ctx);
+long p2p_fixed_prefix(int nranks);
+cgx_status setup_problem(cgx_ctx *ctx, int n);       // allocate the shards of an n x n problem (contents: caller)
+
+// cgx_matrix.cpp
+cgx_status alloc_dia(cgx_ctx *ctx, Shard &s, const std::vector<int> &offs);
+
+// cgx_solve.cpp
+cgx_status p2p_allgather(cgx_ctx *ctx, int chan, const double *src, int count, double *dst, long dst_stride, int copy_self,
+                         int tail_off = 0, int tail_n = 0, int sum_off = 0);
+cgx_status gather_scalars(cgx_ctx *ctx);
+cgx_status gather_segments(cgx_ctx *ctx, bool with_tail);
+cgx_status run_gemv_plain(cgx_ctx *ctx, Shard &s, const double *v_full);
+cgx_status check_p2p_error(cgx_ctx *ctx);
+
+}  // namespace cgxi

@@ -1,5 +1,5 @@
 // cgx_kernels.h -- launch interface of the CDNA4 (gfx950) kernels of the CG hot path.
-// Host code in cgx_solver.cpp sees only these plain functions; all device code is in cgx_kernels.hip.
+// The host code (cgx_context / cgx_matrix / cgx_solve / cgx_probe .cpp) sees only these plain functions; all device code is in cgx_kernels.hip.
 #pragma once
 
 #include <hip/hip_runtime.h>

@@ -1,0 +1,158 @@
+// cgx_probe.cpp -- kernel probes of include/cgx.h: the individual hot ops through the C ABI, for the parity tests.
+#include "cgx_internal.h"
+
+#include <algorithm>
+#include <cctype>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace cgxi;
+
+extern "C" {
+
+// ---- kernel probes -------------------------------------------------------------------------------------
+cgx_status cgx_probe_gemv(cgx_ctx *ctx, const double *p, double *y, double *pAp)
+{
+    if (!ctx || !p || !y) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_probe_gemv: bad argument");
+    if (!ctx->have_matrix) return fail(ctx, CGX_ERR_BAD_ARG, "no matrix");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    double total = 0.0;
+    for (auto &s : ctx->shards) {
+        HIP_TRY(ctx, hipMemsetAsync(s.sc, 0, sizeof(Scalars), st));
+        HIP_TRY(ctx, hipMemcpyAsync(s.p[0], p, (size_t)ctx->n * sizeof(double), hipMemcpyHostToDevice, st));
+        CGX_TRY(run_gemv_plain(ctx, s, s.p[0]));
+        HIP_TRY(ctx, cgx::launch_reduce_partials(s.k1_part(), s.plan.grid, &s.sc->local[cgx::kSlotConj], st));
+        double part = 0.0;
+        if (s.rows > 0)
+            HIP_TRY(ctx, hipMemcpyAsync(y + s.row0, s.Ap(), (size_t)s.rows * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipMemcpyAsync(&part, &s.sc->local[cgx::kSlotConj], sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        total += part;
+    }
+    if (pAp) *pAp = total;
+    return CGX_OK;
+}
+
+cgx_status cgx_probe_time_gemv(cgx_ctx *ctx, int reps, double *ms_per_launch)
+{
+    if (!ctx || reps <= 0 || !ms_per_launch) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_probe_time_gemv: bad argument");
+    if (!ctx->have_matrix) return fail(ctx, CGX_ERR_BAD_ARG, "no matrix");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    hipEvent_t e0, e1;
+    HIP_TRY(ctx, hipEventCreate(&e0));
+    HIP_TRY(ctx, hipEventCreate(&e1));
+    for (auto &s : ctx->shards) HIP_TRY(ctx, hipMemsetAsync(s.sc, 0, sizeof(Scalars), st));
+    for (auto &s : ctx->shards) CGX_TRY(run_gemv_plain(ctx, s, s.p[0]));   // warm
+    HIP_TRY(ctx, hipEventRecord(e0, st));
+    for (int i = 0; i < reps; ++i)
+        for (auto &s : ctx->shards) CGX_TRY(run_gemv_plain(ctx, s, s.p[0]));
+    HIP_TRY(ctx, hipEventRecord(e1, st));
+    HIP_TRY(ctx, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    *ms_per_launch = (double)ms / reps / (double)ctx->shards.size();
+    return CGX_OK;
+}
+
+cgx_status cgx_probe_vector_ops(cgx_ctx *ctx, int n, double alpha, double beta, double *x, double *r, double *p,
+                                const double *Ap, double *rr)
+{
+    if (!ctx || n <= 0 || !x || !r || !p || !Ap) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_probe_vector_ops: bad argument");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    // A single-shard problem of length n around the PRODUCTION kernels: K3 for x/r/r.r, then the fused K1 of
+    // the next iteration (on a 1 x n zero matrix) for p = r + beta p.
+    const long lda = ((long)n + 15) / 16 * 16;
+    const int Sr = std::max((n + 1) / 2 * 2, 2), S = Sr + 2;      // Ap segment: [Ap (Sr) | one partial, pad]
+    const size_t bytes = (size_t)n * sizeof(double), vbytes = (size_t)lda * sizeof(double);
+    const int grid = cgx::update_xr_grid(n);
+    double *dx = nullptr, *dp0 = nullptr, *dp1 = nullptr, *dap = nullptr, *drb = nullptr, *dpart = nullptr, *dA = nullptr,
+           *dAp1 = nullptr;
+    Scalars *dsc = nullptr;
+    HIP_TRY(ctx, hipMalloc(&dx, bytes));
+    HIP_TRY(ctx, hipMalloc(&dp0, vbytes));
+    HIP_TRY(ctx, hipMalloc(&dp1, vbytes));
+    HIP_TRY(ctx, hipMalloc(&dap, (size_t)S * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc(&drb, (size_t)(lda + grid) * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc(&dpart, (size_t)(grid + 8) * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc(&dA, vbytes));
+    HIP_TRY(ctx, hipMalloc(&dAp1, 64 * sizeof(double)));
+    HIP_TRY(ctx, hipMalloc(&dsc, sizeof(Scalars)));
+    cgx::SegView apv{dap, S, Sr, n, 1, n, 0, 0, 0, 0};
+    cgx::seg_finalize(&apv);
+    cgx::SegView rv{drb, (int)lda + grid, (int)lda, n, 1, n, 0, 0, 0, 0};
+    cgx::seg_finalize(&rv);
+    // Force the wanted alpha: with rsold = alpha and p.Ap = 1, K3 computes alpha / max(1, alpha*1e-14) = alpha.
+    Scalars hs{};
+    hs.rs[0] = alpha;
+    const double one = 1.0;
+    HIP_TRY(ctx, hipMemsetAsync(dp0, 0, vbytes, st));
+    HIP_TRY(ctx, hipMemsetAsync(dp1, 0, vbytes, st));
+    HIP_TRY(ctx, hipMemsetAsync(dap, 0, (size_t)S * sizeof(double), st));
+    HIP_TRY(ctx, hipMemsetAsync(drb, 0, (size_t)(lda + grid) * sizeof(double), st));
+    HIP_TRY(ctx, hipMemsetAsync(dA, 0, vbytes, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dsc, &hs, sizeof hs, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dx, x, bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(drb, r, bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dp0, p, bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dap, Ap, bytes, hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemcpyAsync(dap + Sr, &one, sizeof(double), hipMemcpyHostToDevice, st));   // the one p.Ap "partial"
+    HIP_TRY(ctx, cgx::launch_update_xr(n, n, 0, dp0, apv, 0, 1, dx, rv, dsc, 0, dpart, st));
+    std::vector<double> rr_parts_h((size_t)grid);
+    HIP_TRY(ctx, hipMemcpyAsync(rr_parts_h.data(), drb + lda, (size_t)grid * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(x, dx, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipMemcpyAsync(r, drb, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    double rr_host = 0.0;
+    for (double v : rr_parts_h) rr_host += v;
+    // Force the wanted beta: rsold = 1, the r.r partials = {beta, 0, ...}  =>  K1(k=1) computes beta/1.
+    HIP_TRY(ctx, hipMemcpyAsync(&dsc->rs[0], &one, sizeof(double), hipMemcpyHostToDevice, st));
+    HIP_TRY(ctx, hipMemsetAsync(drb + lda, 0, (size_t)grid * sizeof(double), st));
+    HIP_TRY(ctx, hipMemcpyAsync(drb + lda, &beta, sizeof(double), hipMemcpyHostToDevice, st));
+    cgx::GemvPlan plan = cgx::plan_gemv(ctx->cfg.gemv_variant, 1, (int)lda);
+    HIP_TRY(ctx, cgx::launch_gemv_fused(plan, dA, lda, 1, 0, dp0, dp1, rv, dAp1, dAp1 + 8, dsc, 1, -1.0 /* never converges */, st));
+    HIP_TRY(ctx, hipMemcpyAsync(p, dp1, bytes, hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (rr) *rr = rr_host;
+    (void)hipFree(dx); (void)hipFree(dp0); (void)hipFree(dp1); (void)hipFree(dap); (void)hipFree(drb);
+    (void)hipFree(dpart); (void)hipFree(dA); (void)hipFree(dAp1); (void)hipFree(dsc);
+    return CGX_OK;
+}
+
+cgx_status cgx_probe_get_matrix_rows(cgx_ctx *ctx, int local_shard, double *A_out, int *row0, int *rows)
+{
+    if (!ctx || local_shard < 0 || local_shard >= (int)ctx->shards.size())
+        return fail(ctx, CGX_ERR_BAD_ARG, "cgx_probe_get_matrix_rows: bad shard");
+    if (!ctx->have_matrix) return fail(ctx, CGX_ERR_BAD_ARG, "no matrix");
+    Shard &s = ctx->shards[local_shard];
+    if (row0) *row0 = s.row0;
+    if (rows) *rows = s.rows;
+    if (A_out && s.rows > 0 && ctx->banded) {
+        // expand the diagonals on the host (a test probe, small sizes)
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        std::vector<double> vals((size_t)std::max(s.dia.ndiag, 1) * (size_t)s.dia.ld);
+        HIP_TRY(ctx, hipMemcpy(vals.data(), s.dia_vals, vals.size() * sizeof(double), hipMemcpyDeviceToHost));
+        std::fill(A_out, A_out + (size_t)s.rows * ctx->n, 0.0);
+        for (int t = 0; t < s.dia.ndiag; ++t)
+            for (int i = 0; i < s.rows; ++i) {
+                const long j = (long)s.row0 + i + s.dia.off[t];
+                if (j >= 0 && j < ctx->n) A_out[(size_t)i * ctx->n + (size_t)j] = vals[(size_t)t * s.dia.ld + i];
+            }
+    } else if (A_out && s.rows > 0) {
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        HIP_TRY(ctx, hipMemcpy2D(A_out, (size_t)ctx->n * sizeof(double), s.A, (size_t)ctx->lda * sizeof(double),
+                                 (size_t)ctx->n * sizeof(double), (size_t)s.rows, hipMemcpyDeviceToHost));
+    }
+    return CGX_OK;
+}
+
+}  // extern "C"

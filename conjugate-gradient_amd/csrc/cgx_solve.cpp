@@ -1,0 +1,362 @@
+// cgx_solve.cpp -- the exchanges and the CG driver loop behind include/cgx.h (begin / steps / end / solve).
+//
+// Reference path: CGSolver::solve, code/MPI/cg.cc:38-156 (citations are file:line under /root/reference).
+// Design (MI355X-first, not a translation):
+//   * the row block of A, b, x, r, Ap and the replicated p live in HBM for the life of the problem;
+//   * rsold/rsnew/alpha/beta and the convergence flag stay on the device (cgx::Scalars): the host only
+//     enqueues kernels and polls one int every `check_every` iterations, so the stream never drains;
+//   * after convergence every kernel of the remaining enqueued iterations exits at its first
+//     instruction, which reproduces the reference's `break` (cg.cc:120-121) exactly;
+//   * one iteration = two kernels (K1 fused GEMV, K3 x/r update) and ONE exchange: an in-place all-gather of
+//     equal segments [Ap slice | p.Ap partials] replaces MPI_Allreduce(p.Ap), MPI_Allreduce(r.r) and
+//     MPI_Allgatherv(p): r and p are replicated, every rank updates all of r from the gathered Ap, reduces r.r
+//     over all n rows in one fixed order (bit-identical everywhere) and forms p = r + beta p inside the next K1.
+#include "cgx_internal.h"
+
+#include <algorithm>
+#include <cctype>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace cgxi;
+
+namespace cgxi {
+
+// ---- collectives ---------------------------------------------------------------------------------
+
+// CGX_COMM_P2P: one lean all-gather kernel over the IPC-mapped mailboxes (cgx_kernels.hip).
+cgx_status p2p_allgather(cgx_ctx *ctx, int chan, const double *src, int count, double *dst, long dst_stride,
+                         int copy_self, int tail_off, int tail_n, int sum_off)
+{
+    if (!ctx->p2p_ready) return fail(ctx, CGX_ERR_P2P, "cgx_p2p_import has not been called");
+    if ((long)(count + (tail_n > 0 ? 1 : 0)) * 8 > ctx->mv.slot_bytes[chan])
+        return fail(ctx, CGX_ERR_P2P, "p2p payload larger than its slot");
+    const unsigned long long epoch = ++ctx->p2p_epoch[chan];
+    HIP_TRY(ctx, cgx::launch_mailbox_allgather(ctx->mv, chan, epoch, src, count, tail_off, tail_n, dst, dst_stride, sum_off,
+                                               copy_self, ctx->p2p_timeout_ticks, ctx->d_p2p_err, ctx->stream));
+    return CGX_OK;
+}
+
+// Scalars: every shard contributes sc->local[kSlots]; afterwards every shard's gathered[] holds all of them.
+// Replaces MPI_Allreduce (cg.cc:92,106,117).  In SELF mode the consumers read sc->local directly.
+cgx_status gather_scalars(cgx_ctx *ctx)
+{
+    switch (ctx->cfg.comm_mode) {
+    case CGX_COMM_SELF:
+        return CGX_OK;
+    case CGX_COMM_LOOPBACK:
+        HIP_TRY(ctx, cgx::launch_loopback_gather(ctx->d_gathered_ptrs, ctx->d_scalar_ptrs, ctx->nranks, ctx->stream));
+        return CGX_OK;
+    case CGX_COMM_P2P: {
+        Shard &s = ctx->shards[0];
+        return p2p_allgather(ctx, 2, s.sc->local, cgx::kSlots, s.gathered, cgx::kSlots, 1);
+    }
+    default: {
+        Shard &s = ctx->shards[0];
+        NCCL_TRY(ctx, ctx->rccl->AllGather(s.sc->local, s.gathered, cgx::kSlots, ncclDouble, ctx->comm, ctx->stream));
+        return CGX_OK;
+    }
+    }
+}
+
+// THE exchange of an iteration: every shard's own segment [Ap slice | p.Ap partials] inside its apg is current;
+// afterwards all P segments are.  Replaces MPI_Allreduce (cg.cc:106) and MPI_Allgatherv (cg.cc:135-136); segments
+// have the same size on every rank, so N % P != 0 needs no special case.  with_tail = false moves the slices only
+// (used for the final gather of x, MPI_Gatherv cg.cc:140-142).
+cgx_status gather_segments(cgx_ctx *ctx, bool with_tail)
+{
+    const size_t S = (size_t)ctx->seg_S;
+    switch (ctx->cfg.comm_mode) {
+    case CGX_COMM_SELF:
+        return CGX_OK;
+    case CGX_COMM_LOOPBACK:
+        for (auto &dst : ctx->shards)
+            for (auto &src : ctx->shards)
+                if (dst.rank != src.rank)
+                    HIP_TRY(ctx, hipMemcpyAsync(dst.apg + src.rank * S, src.apg + src.rank * S, S * sizeof(double),
+                                                hipMemcpyDeviceToDevice, ctx->stream));
+        return CGX_OK;
+    case CGX_COMM_P2P: {
+        // the exchange kernel folds this rank's partials and ships [Ap slice | one double]
+        Shard &s = ctx->shards[0];
+        return p2p_allgather(ctx, 1, s.Ap(), ctx->seg_Sr, s.apg, ctx->seg_S, 0, ctx->seg_Sr, with_tail ? ctx->npart : 0,
+                             ctx->seg_Sr + ctx->npart);
+    }
+    default: {
+        Shard &s = ctx->shards[0];
+        NCCL_TRY(ctx, ctx->rccl->AllGather(s.Ap(), s.apg, S, ncclDouble, ctx->comm, ctx->stream));
+        return CGX_OK;
+    }
+    }
+}
+
+}  // namespace cgxi
+
+namespace {
+
+// ---- K1 with optional event bracketing -----------------------------------------------------------
+cgx_status take_event(cgx_ctx *ctx, hipEvent_t *out)
+{
+    if (ctx->ev_used == ctx->ev_pool.size()) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->ev_pool.push_back(e);
+    }
+    *out = ctx->ev_pool[ctx->ev_used++];
+    return CGX_OK;
+}
+
+}  // namespace
+
+namespace cgxi {
+
+// K1, plain form (vector given): initial residual, DEBUG verification, probes.
+cgx_status run_gemv_plain(cgx_ctx *ctx, Shard &s, const double *v_full)
+{
+    if (ctx->banded)
+        HIP_TRY(ctx, cgx::launch_spmv_dia_plain(s.plan, s.dia, s.rows, s.row0, ctx->n, v_full, s.Ap(), s.k1_part(), s.sc,
+                                                ctx->stream));
+    else
+        HIP_TRY(ctx, cgx::launch_gemv_plain(s.plan, s.A, ctx->lda, s.rows, v_full, v_full + s.row0, s.Ap(), s.k1_part(),
+                                            s.sc, ctx->stream));
+    return CGX_OK;
+}
+
+// K1, fused form of iteration k; every `profile_gemv`-th launch is bracketed with HIP events.
+cgx_status run_gemv_fused(cgx_ctx *ctx, Shard &s, int k)
+{
+    const int every = ctx->cfg.profile_gemv;
+    // at most 2048 timed launches per cgx_solve_steps call: the event pool stays bounded however long the run is
+    const bool timed = every > 0 && (ctx->gemv_seq++ % every) == 0 && ctx->ev_used + 2 <= 4096;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (timed) {
+        CGX_TRY(take_event(ctx, &e0));
+        CGX_TRY(take_event(ctx, &e1));
+        HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+    }
+    if (ctx->banded)
+        HIP_TRY(ctx, cgx::launch_spmv_dia_fused(s.plan, s.dia, s.rows, s.row0, ctx->n, ctx->lda, s.p[k & 1], s.p[(k + 1) & 1],
+                                                s.rv, s.Ap(), s.k1_part(), s.sc, k, ctx->tol, ctx->stream));
+    else
+        HIP_TRY(ctx, cgx::launch_gemv_fused(s.plan, s.A, ctx->lda, s.rows, s.row0, s.p[k & 1], s.p[(k + 1) & 1], s.rv,
+                                            s.Ap(), s.k1_part(), s.sc, k, ctx->tol, ctx->stream));
+    if (timed) HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+    return CGX_OK;
+}
+
+// Fold the recorded event pairs into the running K1 statistics (call after a stream sync).
+cgx_status harvest_gemv_events(cgx_ctx *ctx)
+{
+    for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev_pool[i], ctx->ev_pool[i + 1]));
+        ctx->gemv_ms_sum += ms;
+        if (ctx->gemv_launches == 0 || ms < ctx->gemv_ms_min) ctx->gemv_ms_min = ms;
+        ctx->gemv_launches++;
+    }
+    ctx->ev_used = 0;
+    return CGX_OK;
+}
+
+// ---- one body of the loop cg.cc:96-137: two kernels, one exchange ------------------------------------
+cgx_status enqueue_iteration(cgx_ctx *ctx, int k)
+{
+    hipStream_t st = ctx->stream;
+    // tail of iteration k-1 (cg.cc:117-132) + GEMV and p.Ap partials of iteration k (cg.cc:100-105)
+    for (auto &s : ctx->shards) CGX_TRY(run_gemv_fused(ctx, s, k));
+    if (ctx->cfg.comm_mode == CGX_COMM_P2P && !ctx->cfg.p2p_separate_exchange) {
+        // direct peer exchange folded into K3: the iteration is two kernels, no collective launch at all
+        Shard &s = ctx->shards[0];
+        if (!ctx->p2p_ready) return fail(ctx, CGX_ERR_P2P, "cgx_p2p_import has not been called");
+        const unsigned long long epoch = ++ctx->p2p_epoch[1];
+        HIP_TRY(ctx, cgx::launch_update_xr_p2p(ctx->n, s.rows, s.row0, s.p[(k + 1) & 1], s.apv, ctx->npart, ctx->mv, 1, epoch,
+                                               s.x, s.rv, s.sc, k & 1, ctx->p2p_timeout_ticks, ctx->d_p2p_err, st));
+        return CGX_OK;
+    }
+    CGX_TRY(gather_segments(ctx, true));                                                             // cg.cc:106
+    const bool folded = ctx->cfg.comm_mode == CGX_COMM_P2P;   // the exchange kernel already folded each rank's partials
+    for (auto &s : ctx->shards)
+        HIP_TRY(ctx, cgx::launch_update_xr(ctx->n, s.rows, s.row0, s.p[(k + 1) & 1], s.apv, folded ? ctx->npart : 0,
+                                           folded ? 1 : ctx->npart, s.x, s.rv, s.sc, k & 1, s.partials, st));   // cg.cc:105-116
+    return CGX_OK;
+}
+
+// After a stream sync: did any bounded wait of the direct peer exchange expire?
+cgx_status check_p2p_error(cgx_ctx *ctx)
+{
+    if (ctx->cfg.comm_mode != CGX_COMM_P2P || !ctx->d_p2p_err) return CGX_OK;
+    int e = 0;
+    HIP_TRY(ctx, hipMemcpy(&e, ctx->d_p2p_err, sizeof(int), hipMemcpyDeviceToHost));
+    if (e) return fail(ctx, CGX_ERR_P2P, "direct peer exchange: a wait for a peer's flag expired (peer dead or IPC not coherent)");
+    return CGX_OK;
+}
+
+cgx_status read_flags_sync(cgx_ctx *ctx)
+{
+    Shard &s = ctx->shards[0];
+    int flags[2] = {0, 0};
+    HIP_TRY(ctx, hipMemcpyAsync(flags, &s.sc->done, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->done = flags[0] != 0;
+    ctx->k_final = flags[1];
+    return check_p2p_error(ctx);
+}
+
+}  // namespace cgxi
+
+extern "C" {
+
+// ---- solve, cg.cc:38-156 -----------------------------------------------------------------------------
+cgx_status cgx_solve_begin(cgx_ctx *ctx, const double *x0)
+{
+    if (!ctx || !x0) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_solve_begin: bad argument");
+    if (!ctx->have_matrix || !ctx->have_b) return fail(ctx, CGX_ERR_BAD_ARG, "matrix and source term must be set before solve");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->t_begin = wall_now();
+    ctx->t_loop = 0;
+    ctx->k = 0;
+    ctx->done = false;
+    ctx->k_final = 0;
+    ctx->ev_used = 0;
+    ctx->gemv_ms_sum = ctx->gemv_ms_min = 0;
+    ctx->gemv_launches = 0;
+    ctx->gemv_seq = 0;
+    hipStream_t st = ctx->stream;
+    const int n = ctx->n;
+    const size_t vec_bytes = (size_t)ctx->lda * sizeof(double);
+    for (auto &s : ctx->shards) {
+        HIP_TRY(ctx, hipMemsetAsync(s.sc, 0, sizeof(Scalars), st));
+        HIP_TRY(ctx, hipMemsetAsync(s.apg, 0, (size_t)ctx->nranks * ctx->seg_S * sizeof(double), st));
+        HIP_TRY(ctx, hipMemsetAsync(s.rbuf, 0, (size_t)s.rv.S * sizeof(double), st));
+        // x (initial guess) replicated for the first GEMV, x_sub = x[rows]  (cg.cc:72, 80)
+        HIP_TRY(ctx, hipMemcpyAsync(s.p[0], x0, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+        if (s.rows > 0)
+            HIP_TRY(ctx, hipMemcpyAsync(s.x, s.p[0] + s.row0, (size_t)s.rows * sizeof(double), hipMemcpyDeviceToDevice, st));
+    }
+    for (auto &s : ctx->shards) CGX_TRY(run_gemv_plain(ctx, s, s.p[0]));                             // cg.cc:79-81
+    CGX_TRY(gather_segments(ctx, false));
+    for (auto &s : ctx->shards)
+        HIP_TRY(ctx, cgx::launch_init_residual(n, s.b_full, s.apv, s.rv, s.partials, st));           // cg.cc:82
+    for (auto &s : ctx->shards) {
+        // p_old of iteration 0 is 0, so K1(0) forms p = r + 0*0 = r  (p_sub = r_sub, cg.cc:85)
+        HIP_TRY(ctx, hipMemsetAsync(s.p[0], 0, vec_bytes, st));
+        HIP_TRY(ctx, hipMemsetAsync(s.p[1], 0, vec_bytes, st));
+    }
+    ctx->in_solve = true;
+    return CGX_OK;
+}
+
+cgx_status cgx_solve_steps(cgx_ctx *ctx, int nsteps, int *done_out)
+{
+    if (!ctx || !ctx->in_solve) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_solve_steps outside begin/end");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const double t0 = wall_now();
+    // K1 statistics describe the most recent steps call (bench.py: the timed region, not the warmup)
+    ctx->ev_used = 0;
+    ctx->gemv_ms_sum = ctx->gemv_ms_min = 0;
+    ctx->gemv_launches = 0;
+    ctx->gemv_seq = 0;   // the first K1 of every steps call is always one of the sampled launches
+    const int every = ctx->cfg.check_every;
+    int slot = 0;
+    bool pending[2] = {false, false};
+    bool stop = ctx->done;
+    int left = std::min(nsteps, ctx->max_iter - ctx->k);
+    while (left > 0 && !stop) {
+        const int batch = std::min(left, every);
+        for (int i = 0; i < batch; ++i) CGX_TRY(enqueue_iteration(ctx, ctx->k + i));
+        ctx->k += batch;
+        left -= batch;
+        // publish {done,k_final} after this batch; look at the batch BEFORE it, so one batch stays queued
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->h_flags + 2 * slot, &ctx->shards[0].sc->done, 2 * sizeof(int),
+                                    hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipEventRecord(ctx->flag_ev[slot], ctx->stream));
+        pending[slot] = true;
+        slot ^= 1;
+        if (pending[slot]) {
+            HIP_TRY(ctx, hipEventSynchronize(ctx->flag_ev[slot]));
+            pending[slot] = false;
+            if (ctx->h_flags[2 * slot]) stop = true;   // identical on every rank: rsnew is bit-identical (cg.cc:117-121)
+        }
+    }
+    CGX_TRY(read_flags_sync(ctx));
+    if (ctx->cfg.profile_gemv) CGX_TRY(harvest_gemv_events(ctx));
+    ctx->t_loop += wall_now() - t0;
+    if (done_out) *done_out = ctx->done ? 1 : 0;
+    return CGX_OK;
+}
+
+cgx_status cgx_solve_end(cgx_ctx *ctx, double *x, cgx_result *res)
+{
+    if (!ctx || !ctx->in_solve) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_solve_end outside begin");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    // The convergence test of the last enqueued iteration is normally done by the NEXT K1; when the loop
+    // ran out there is none, so close it here (cg.cc:117-121,132).
+    for (auto &s : ctx->shards) HIP_TRY(ctx, cgx::launch_close_iteration(s.sc, s.rv, ctx->k, ctx->tol, st));
+    CGX_TRY(read_flags_sync(ctx));
+    const int k_exit = ctx->done ? ctx->k_final : ctx->k;
+
+    // Gather x (MPI_Gatherv, cg.cc:140-142) through the exchange segments, then the DEBUG verification
+    // (cg.cc:144-151) with the same K1, distributed over the shards instead of rank 0 alone.
+    for (auto &s : ctx->shards)
+        if (s.rows > 0)
+            HIP_TRY(ctx, hipMemcpyAsync(s.Ap(), s.x, (size_t)s.rows * sizeof(double), hipMemcpyDeviceToDevice, st));
+    CGX_TRY(gather_segments(ctx, false));
+    for (auto &s : ctx->shards) HIP_TRY(ctx, cgx::launch_unpack_segments(s.apv, s.p[0], ctx->lda, st));
+    for (auto &s : ctx->shards) CGX_TRY(run_gemv_plain(ctx, s, s.p[0]));
+    for (auto &s : ctx->shards)
+        HIP_TRY(ctx, cgx::launch_debug_norms(s.rows, s.Ap(), s.b_full + s.row0, s.x, s.partials, st));
+    for (auto &s : ctx->shards)
+        HIP_TRY(ctx, cgx::launch_reduce_partials3(s.partials, cgx::update_xr_grid(s.rows), s.sc->local, st));
+    CGX_TRY(gather_scalars(ctx));
+
+    Shard &s0 = ctx->shards[0];
+    Scalars hs;
+    std::vector<double> hg((size_t)cgx::kMaxRanks * cgx::kSlots, 0.0);
+    HIP_TRY(ctx, hipMemcpyAsync(&hs, s0.sc, sizeof hs, hipMemcpyDeviceToHost, st));
+    if (ctx->cfg.comm_mode != CGX_COMM_SELF)
+        HIP_TRY(ctx, hipMemcpyAsync(hg.data(), s0.gathered, hg.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    if (x) HIP_TRY(ctx, hipMemcpyAsync(x, s0.p[0], (size_t)ctx->n * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (ctx->cfg.comm_mode == CGX_COMM_SELF)
+        for (int v = 0; v < cgx::kSlots; ++v) hg[v] = hs.local[v];
+    double sums[3] = {0, 0, 0};
+    for (int v = 0; v < 3; ++v)
+        for (int q = 0; q < ctx->nranks; ++q) sums[v] += hg[(size_t)q * cgx::kSlots + v];
+
+    ctx->in_solve = false;
+    if (res) {
+        memset(res, 0, sizeof *res);
+        res->iterations = k_exit;
+        res->converged = ctx->done ? 1 : 0;
+        res->residual_prev = std::sqrt(hs.rs[k_exit & 1]);         // sqrt(rsold) as printed, cg.cc:152-153
+        res->residual_last = std::sqrt(hs.rs[(k_exit + 1) & 1]);
+        if (!ctx->done) res->residual_last = res->residual_prev;    // loop ran out: rsold == rsnew (cg.cc:132)
+        res->x_norm = std::sqrt(sums[2]);
+        res->rel_residual = std::sqrt(sums[0]) / std::sqrt(sums[1]);
+        res->seconds_solve = wall_now() - ctx->t_begin;
+        res->seconds_loop = ctx->t_loop;
+        res->gemv_launches = ctx->gemv_launches;
+        res->gemv_ms_avg = ctx->gemv_launches ? ctx->gemv_ms_sum / (double)ctx->gemv_launches : 0.0;
+        res->gemv_ms_min = ctx->gemv_ms_min;
+        res->gemv_bytes = ctx->banded ? 8.0 * ((double)s0.rows * s0.dia.ndiag + 2.0 * s0.rows)
+                                      : 8.0 * ((double)s0.rows * ctx->n + ctx->n + s0.rows);
+    }
+    return CGX_OK;
+}
+
+cgx_status cgx_solve(cgx_ctx *ctx, double *x, cgx_result *res)
+{
+    if (!ctx || !x) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_solve: bad argument");
+    CGX_TRY(cgx_solve_begin(ctx, x));
+    int done = 0;
+    CGX_TRY(cgx_solve_steps(ctx, ctx->max_iter, &done));
+    return cgx_solve_end(ctx, x, res);
+}
+
+}  // extern "C"

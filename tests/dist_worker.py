@@ -1,7 +1,7 @@
 """Worker for tests/test_distributed_cpu.py: one OS process per rank over gloo (CPU).
 
 It runs the row-block CG with the SAME exchange protocol libcgx uses (conjugate-gradient_amd/csrc/
-cgx_solver.cpp: enqueue_iteration / gather_segments), with the oracle's GEMV standing in for K1:
+cgx_solve.cpp: enqueue_iteration / gather_segments), with the oracle's GEMV standing in for K1:
   * one all-gather per iteration of equal segments [Ap slice | p.Ap partial]; p.Ap = rank-ordered sum;
   * r and p are replicated: every rank updates all of r and reduces r.r itself, identically;
   * break: every rank must see bit-identical r.r and leave the loop at the same k.
