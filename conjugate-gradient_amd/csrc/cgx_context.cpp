@@ -66,6 +66,8 @@ void free_problem(cgx_ctx *ctx)
     ctx->shards.clear();
     (void)hipFree(ctx->d_gathered_ptrs);
     (void)hipFree(ctx->d_scalar_ptrs);
+    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
+    ctx->h_stage = nullptr;
     ctx->d_gathered_ptrs = nullptr;
     ctx->d_scalar_ptrs = nullptr;
     ctx->have_matrix = ctx->have_b = false;
@@ -114,6 +116,9 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
     }
     free_problem(ctx);
     ctx->m = ctx->n = n;
+    if (n <= (8 << 20) &&
+        hipHostMalloc(reinterpret_cast<void **>(&ctx->h_stage), (size_t)n * sizeof(double), hipHostMallocDefault) != hipSuccess)
+        ctx->h_stage = nullptr;   // not fatal: the copies fall back to the caller's pageable buffer
     ctx->max_iter = n;   // m_maxIter = size, code/MPI/cg.cc:172
     ctx->lda = default_lda(ctx, n);
     ctx->start_rows.assign(ctx->nranks, 0);

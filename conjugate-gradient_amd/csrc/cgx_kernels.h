@@ -91,6 +91,9 @@ hipError_t launch_init_residual(int n, const double *b_full, SegView apv, SegVie
 // v_full[c] = segment value of column c (c < n), 0 for the pad: turns gathered slices into a replicated vector.
 hipError_t launch_unpack_segments(SegView seg, double *v_full, long lda, hipStream_t s);
 
+// dst[0..count) = src[0..count) by a kernel; dst or src may be pinned host memory.
+hipError_t launch_copy_doubles(double *dst, const double *src, long count, hipStream_t s);
+
 // DEBUG block (cg.cc:144-151): partials[3*wg + {0,1,2}] = sum (Ax-b)^2, b^2, x^2 over this shard's rows.
 hipError_t launch_debug_norms(int count, const double *Ax, const double *b, const double *x, double *partials,
                               hipStream_t s);

@@ -548,6 +548,13 @@ __global__ __launch_bounds__(256) void k_init_residual(int n, const double *__re
     if (threadIdx.x == 0) r[rv.Sr + blockIdx.x] = rr;   // same slots as K3's partials: K1(0) folds them (cg.cc:91-92)
 }
 
+// dst[0..count) = src[0..count); either side may be pinned host memory (x0 in / x out of a solve: a kernel instead of
+// a copy-engine transfer, whose first use in a process costs ~8 ms -- inside the reference's timing window).
+__global__ __launch_bounds__(256) void k_copy_doubles(double *__restrict__ dst, const double *__restrict__ src, long count)
+{
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
+
 __global__ __launch_bounds__(256) void k_unpack_segments(SegView sv, double *__restrict__ v_full, long lda)
 {
     for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < lda; c += (long)gridDim.x * 256)
@@ -1312,6 +1319,15 @@ hipError_t launch_reduce_partials3(const double *partials, int n, double *out3, 
 hipError_t launch_init_residual(int n, const double *b_full, SegView apv, SegView rv, double *partials, hipStream_t s)
 {
     hipLaunchKernelGGL(k_init_residual, dim3(update_xr_grid(n)), dim3(256), 0, s, n, b_full, apv, rv, partials);
+    return hipGetLastError();
+}
+
+hipError_t launch_copy_doubles(double *dst, const double *src, long count, hipStream_t s)
+{
+    if (count <= 0) return hipSuccess;
+    int grid = ceil_div(count, 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(k_copy_doubles, dim3(grid), dim3(256), 0, s, dst, src, count);
     return hipGetLastError();
 }
 

@@ -229,12 +229,18 @@ cgx_status cgx_solve_begin(cgx_ctx *ctx, const double *x0)
     hipStream_t st = ctx->stream;
     const int n = ctx->n;
     const size_t vec_bytes = (size_t)ctx->lda * sizeof(double);
+    const double *x_src = x0;
+    if (ctx->h_stage) {
+        memcpy(ctx->h_stage, x0, (size_t)n * sizeof(double));
+        x_src = ctx->h_stage;
+    }
     for (auto &s : ctx->shards) {
         HIP_TRY(ctx, hipMemsetAsync(s.sc, 0, sizeof(Scalars), st));
         HIP_TRY(ctx, hipMemsetAsync(s.apg, 0, (size_t)ctx->nranks * ctx->seg_S * sizeof(double), st));
         HIP_TRY(ctx, hipMemsetAsync(s.rbuf, 0, (size_t)s.rv.S * sizeof(double), st));
         // x (initial guess) replicated for the first GEMV, x_sub = x[rows]  (cg.cc:72, 80)
-        HIP_TRY(ctx, hipMemcpyAsync(s.p[0], x0, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
+        if (ctx->h_stage) HIP_TRY(ctx, cgx::launch_copy_doubles(s.p[0], ctx->h_stage, n, st));   // reads the pinned buffer over PCIe
+        else HIP_TRY(ctx, hipMemcpyAsync(s.p[0], x_src, (size_t)n * sizeof(double), hipMemcpyHostToDevice, st));
         if (s.rows > 0)
             HIP_TRY(ctx, hipMemcpyAsync(s.x, s.p[0] + s.row0, (size_t)s.rows * sizeof(double), hipMemcpyDeviceToDevice, st));
     }
@@ -321,8 +327,11 @@ cgx_status cgx_solve_end(cgx_ctx *ctx, double *x, cgx_result *res)
     HIP_TRY(ctx, hipMemcpyAsync(&hs, s0.sc, sizeof hs, hipMemcpyDeviceToHost, st));
     if (ctx->cfg.comm_mode != CGX_COMM_SELF)
         HIP_TRY(ctx, hipMemcpyAsync(hg.data(), s0.gathered, hg.size() * sizeof(double), hipMemcpyDeviceToHost, st));
-    if (x) HIP_TRY(ctx, hipMemcpyAsync(x, s0.p[0], (size_t)ctx->n * sizeof(double), hipMemcpyDeviceToHost, st));
+    double *x_dst = (x && ctx->h_stage) ? ctx->h_stage : x;
+    if (x && ctx->h_stage) HIP_TRY(ctx, cgx::launch_copy_doubles(ctx->h_stage, s0.p[0], ctx->n, st));   // writes the pinned buffer
+    else if (x) HIP_TRY(ctx, hipMemcpyAsync(x, s0.p[0], (size_t)ctx->n * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
+    if (x && x_dst != x) memcpy(x, x_dst, (size_t)ctx->n * sizeof(double));
     if (ctx->cfg.comm_mode == CGX_COMM_SELF)
         for (int v = 0; v < cgx::kSlots; ++v) hg[v] = hs.local[v];
     double sums[3] = {0, 0, 0};
