@@ -136,7 +136,7 @@ def comm_unique_id():
     buf = (C.c_ubyte * UNIQUE_ID_BYTES)()
     st = lib().cgx_comm_unique_id(buf)
     if st:
-        raise CgxError(st, lib().cgx_last_error(None).decode())
+        raise CgxError(st, lib().cgx_last_error(None).decode(errors="replace"))
     return bytes(buf)
 
 
@@ -172,14 +172,14 @@ class CGSolver:
         st = L.cgx_create(C.byref(self._h), C.byref(cfg))
         if st:
             self._h = C.c_void_p()
-            raise CgxError(st, L.cgx_last_error(None).decode())
+            raise CgxError(st, L.cgx_last_error(None).decode(errors="replace"))
         self.nranks = nranks
         self.rank = rank
 
     # -- plumbing -------------------------------------------------------------------------------
     def _check(self, st):
         if st:
-            raise CgxError(st, lib().cgx_last_error(self._h).decode())
+            raise CgxError(st, lib().cgx_last_error(self._h).decode(errors="replace"))
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:
