@@ -163,7 +163,15 @@ cgx_status cgx_read_matrix(cgx_ctx *ctx, const char *path)
     for (;;) {   // size line after the % comments, mmio.c:198-206
         if (!fgets(line, sizeof line, f)) return fail(ctx, CGX_ERR_IO, "Matrix Market size line missing");
         if (line[0] == '%') continue;
-        if (sscanf(line, "%d %d %d", &m, &n, &nz) == 3) break;
+        long long lm = 0, ln = 0, lnz = 0;
+        if (sscanf(line, "%lld %lld %lld", &lm, &ln, &lnz) == 3) {   // the reference reads three ints (mmio.c:204)
+            if (lm > 0x7fffffffLL || ln > 0x7fffffffLL || lnz > 0x7fffffffLL || lm < 0 || ln < 0 || lnz < 0)
+                return fail(ctx, CGX_ERR_UNSUPPORTED, "Matrix Market size line does not fit the reference's int sizes");
+            m = (int)lm;
+            n = (int)ln;
+            nz = (int)lnz;
+            break;
+        }
     }
     if (m <= 0 || n <= 0 || nz < 0 || m != n)
         return fail(ctx, CGX_ERR_UNSUPPORTED, "CG needs a square matrix with positive size");
@@ -209,6 +217,7 @@ cgx_status cgx_read_matrix(cgx_ctx *ctx, const char *path)
                 if (field < 2) {
                     const long v = strtol(p, &e, 10);
                     if (e == p) return fail(ctx, CGX_ERR_IO, "Matrix Market entry " + std::to_string(ha.size()) + " unreadable");
+                    if (v < 1 || v > 0x7fffffffL) return fail(ctx, CGX_ERR_IO, "Matrix Market index out of range");
                     (field == 0 ? I : J) = (int)v;
                     ++field;
                 } else {
