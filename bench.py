@@ -13,21 +13,30 @@ prints ONE JSON line.  value = K / t for the whole job (every rank advances the 
 
 Extra objects in the line:
   roofline     -- K1 (the GEMV) against the 8 TB/s HBM peak: algorithmic bytes 8*(rows*N + N + rows) per launch
-                  divided by the mean launch duration measured with HIP events on the library's own stream.
+                  divided by the MEDIAN launch duration of the timed region, measured with HIP events bound to the K1
+                  dispatches on the library's own stream (the first launch after the sync is never a sample).
   cpu_baseline -- the CPU oracle (oracle/cg_oracle.c, a port of the reference's serial path) run for a few
                   iterations of the same workload on one host core (rank 0, 1-GPU runs only).
+  solve_window -- the same K iterations through the reference's own timing window (all of solve(), cg_main.cc:53-55).
+
+Rank 0 ALWAYS prints a line: if no transport produces a result, if an exception escapes, or if a watchdog expires, the line
+has "value": null and an "error" object.
 """
 import argparse
 import json
 import math
 import os
+import signal
 import sys
+import threading
 import time
+import traceback
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+TRAFFIC_FILE = "profiles/k1_hbm_traffic.json"
 
 
 def parse_args():
@@ -44,16 +53,21 @@ def parse_args():
     ap.add_argument("--lda-pad", type=int, default=-1)
     ap.add_argument("--cpu-baseline-iters", type=int, default=20)   # 20-50 loop bodies at N=32768, not 500
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-profile-gemv", action="store_true", help="do not bracket K1 with HIP events")
+    ap.add_argument("--no-profile-gemv", action="store_true", help="do not time K1 with HIP events")
     ap.add_argument("--profile-every", type=int, default=0,
-                    help="event-time every n-th K1 launch (default: 4 on one GPU, 8 on several: the event pair "
-                         "costs ~5 us per timed launch, measured)")
+                    help="event-time every n-th K1 launch (default: every launch when steps <= 64, so that a short "
+                         "window still gives >= 16 samples; else 4 on one GPU, 8 on several)")
+    ap.add_argument("--no-solve-window", action="store_true", help="skip the extra untimed solve() through the reference's window")
+    ap.add_argument("--wireup-timeout", type=float, default=float(os.environ.get("CGX_BENCH_WIREUP_TIMEOUT", "90")),
+                    help="seconds one transport's wire-up stage may take before that transport is dropped")
+    ap.add_argument("--watchdog", type=float, default=float(os.environ.get("CGX_BENCH_WATCHDOG", "480")),
+                    help="seconds after which rank 0 prints a failure line and the process exits")
     return ap.parse_args()
 
 
 def pmc_traffic(n, nranks):
     """HBM bytes per K1 launch from a committed rocprofv3 --pmc pass (profiles/), or None."""
-    path = os.path.join(ROOT, "profiles", "k1_hbm_traffic.json")
+    path = os.path.join(ROOT, TRAFFIC_FILE)
     try:
         rows = json.load(open(path))["rows"]
     except Exception:
@@ -74,6 +88,28 @@ def broadcast_bytes(dist, payload, nbytes, device):
         t = torch.zeros(nbytes, dtype=torch.uint8, device=device)
     dist.broadcast(t, src=0)
     return bytes(t.cpu().tolist())
+
+
+def call_with_timeout(fn, seconds, what):
+    """fn() on a helper thread, at most `seconds`.  A call that does not come back (a hung ncclCommInitRank, a peer
+    that never opens its mailbox) raises TimeoutError here; the helper thread is abandoned (daemon) and the process
+    leaves through os._exit at the end, so it can never hold the driver's limit."""
+    box = {}
+
+    def body():
+        try:
+            box["value"] = fn()
+        except BaseException as e:          # noqa: BLE001 -- re-raised on the calling thread
+            box["error"] = e
+
+    t = threading.Thread(target=body, daemon=True, name="bench-" + what)
+    t.start()
+    t.join(seconds)
+    if t.is_alive():
+        raise TimeoutError("%s did not finish within %.0f s" % (what, seconds))
+    if "error" in box:
+        raise box["error"]
+    return box.get("value")
 
 
 def cpu_baseline(n, iters):
@@ -110,100 +146,157 @@ def cpu_baseline(n, iters):
     return out
 
 
-def main():
-    args = parse_args()
-    # stdout carries the ONE JSON line and nothing else: whatever the libraries print on fd 1 while the run is
-    # going (RCCL's version banner, for one) is sent to stderr instead.
-    sys.stdout.flush()
-    json_fd = os.dup(1)
-    os.dup2(2, 1)
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
-        args.gpus = world
-
-    import numpy as np
-    import torch   # before libcgx: the library then shares the HIP/RCCL instances torch loaded
-    import __graft_entry__ as g
-
-    assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path to time"
-    ndev = torch.cuda.device_count()
-    if local_rank >= ndev:
-        # more ranks than GPUs is only ever a rehearsal on a one-GPU box (RCCL itself refuses duplicate devices)
-        local_rank = local_rank % ndev
-    torch.cuda.set_device(local_rank)
-    pkg = g.load_package()
-
-    dist = None
-    uid = None
-    # Under torch.distributed.run (RANK set) the RCCL path is used even for one rank, so that the launcher
-    # plumbing and the collectives can be rehearsed on a one-GPU box; plain `python bench.py` has no comm.
-    use_comm = world > 1 or ("RANK" in os.environ and os.environ.get("CGX_BENCH_FORCE_SELF") != "1")
-    ctl = "cuda"   # device of the small control-plane tensors
-    if use_comm:
-        import torch.distributed as dist
-        backend = os.environ.get("CGX_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of world > 1 on a one-GPU box
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", rank=rank, world_size=world,
-                                    device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
-            ctl = "cpu"
-
+def problem_size(args, world):
     if args.n:
-        n = args.n
-    elif args.mode == "weak":
-        n = int(math.floor(16384 * math.sqrt(world)))   # code/MPI/cg.run:22-44 rounding rule, N^2/P constant
-    else:
-        n = 32768
-    profile_every = 0 if args.no_profile_gemv else (args.profile_every or (4 if world == 1 else 8))
+        return args.n
+    if args.mode == "weak":
+        return int(math.floor(16384 * math.sqrt(world)))   # code/MPI/cg.run:22-44 rounding rule, N^2/P constant
+    return 32768
 
-    def all_ok(flag):
+
+def base_line(args, world, n):
+    """The fields of the line that do not depend on a measurement (also the body of a failure line)."""
+    return {
+        "metric": "cg_iterations_per_sec",
+        "value": None,
+        "unit": "iterations/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": None,
+        "higher_is_better": True,
+        "scaling": args.mode,
+        "vs_baseline": None,           # the reference publishes seconds only, nothing at this N (BASELINE.md section 1)
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": "generate_lap2d_matrix N=%d, init_source_term(1/N), fixed-iteration dense fp64 CG "
+                        "(BASELINE.json configs[%d])" % (n, 4 if args.mode == "weak" else (2 if world == 1 else 3)),
+            "n": n, "parallelism": "rowblock%d" % world,
+        },
+    }
+
+
+class Bench:
+    """One rank of the measurement.  Every decision that changes the sequence of torch.distributed calls is taken on a
+    rank-reduced value (all_ok), so a local failure can never leave the ranks inside different collectives."""
+
+    def __init__(self, args, world, rank, local_rank, state):
+        self.args, self.world, self.rank, self.local_rank, self.state = args, world, rank, local_rank, state
+        self.dist = None
+        self.ctl = "cuda"       # device of the small control-plane tensors
+        self.n = problem_size(args, world)
+        self.notes = []
+        self.prewarm_iterations = {}
+
+    # ---- plumbing ------------------------------------------------------------------------------------
+    def log(self, msg):
+        print("bench.py rank %d: %s" % (self.rank, msg), file=sys.stderr, flush=True)
+
+    def all_ok(self, flag):
         """True only if `flag` is true on every rank (so that all ranks take the same branch)."""
-        if dist is None:
+        if self.dist is None:
             return bool(flag)
-        t = torch.tensor([1 if flag else 0], dtype=torch.int32, device=ctl)
-        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        t = self.torch.tensor([1 if flag else 0], dtype=self.torch.int32, device=self.ctl)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
         return bool(t.item())
 
-    def sync():
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
+    def sync(self):
+        if self.dist is not None:
+            self.dist.barrier()
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
 
-    def make_solver(transport):
+    def gather_rows(self, values):
+        """Every rank's list of floats -> list over ranks (rank order)."""
+        torch = self.torch
+        mine = torch.tensor(values, dtype=torch.float64, device=self.ctl)
+        if self.dist is None:
+            return [mine.cpu().tolist()]
+        allv = [torch.zeros_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(allv, mine)
+        return [v.cpu().tolist() for v in allv]
+
+    def gather_strings(self, text, width=32):
+        raw = text.encode()[:width].ljust(width, b"\0")
+        rows = self.gather_rows([float(b) for b in raw])
+        return [bytes(int(b) for b in r).rstrip(b"\0").decode(errors="replace") for r in rows]
+
+    # ---- set-up ---------------------------------------------------------------------------------------
+    def init(self):
+        self.state["stage"] = "import torch / init_process_group"
+        import numpy as np
+        import torch   # before libcgx: the library then shares the HIP/RCCL instances torch loaded
+        import __graft_entry__ as g
+        self.np, self.torch, self.g = np, torch, g
+        args, world, rank = self.args, self.world, self.rank
+
+        assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path to time"
+        ndev = torch.cuda.device_count()
+        if self.local_rank >= ndev:
+            # more ranks than GPUs is only ever a rehearsal on a one-GPU box (RCCL itself refuses duplicate devices)
+            self.local_rank = self.local_rank % ndev
+        torch.cuda.set_device(self.local_rank)
+        self.pkg = g.load_package()
+
+        # Under torch.distributed.run (RANK set) the RCCL path is used even for one rank, so that the launcher
+        # plumbing and the collectives can be rehearsed on a one-GPU box; plain `python bench.py` has no comm.
+        self.use_comm = world > 1 or ("RANK" in os.environ and os.environ.get("CGX_BENCH_FORCE_SELF") != "1")
+        if self.use_comm:
+            import torch.distributed as dist
+            self.backend = os.environ.get("CGX_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of world > 1 on a one-GPU box
+
+            def init_pg():
+                if self.backend == "nccl":
+                    dist.init_process_group(backend="nccl", rank=rank, world_size=world,
+                                            device_id=torch.device("cuda", self.local_rank))
+                else:
+                    dist.init_process_group(backend=self.backend, rank=rank, world_size=world)
+            call_with_timeout(init_pg, max(self.args.wireup_timeout, 120.0), "init_process_group")
+            if self.backend != "nccl":
+                self.ctl = "cpu"
+            self.dist = dist
+        if args.no_profile_gemv:
+            self.profile_every = 0
+        elif args.profile_every:
+            self.profile_every = args.profile_every
+        else:
+            self.profile_every = 1 if args.steps <= 64 else (4 if world == 1 else 8)
+
+    def make_solver(self, transport):
         """transport: 'self' | 'rccl' | 'p2p' | 'p2p-sep'.  Returns a ready solver or None (same answer on every rank).
         The wire-up is cut into stages; after each one all ranks agree (all_ok) whether to go on, so that a failure on
-        one rank can never leave the others inside a different torch.distributed call."""
-        common = dict(nranks=world, rank=rank, device=local_rank, gemv_variant=args.variant, lda_pad=args.lda_pad,
-                      profile_gemv=profile_every)
-        box = {"s": None, "uid": None, "handle": None, "all_handles": None}
+        one rank can never leave the others inside a different torch.distributed call.  Every stage that can block on a
+        peer is bounded by --wireup-timeout."""
+        pkg, dist, world, rank, n, args = self.pkg, self.dist, self.world, self.rank, self.n, self.args
+        common = dict(nranks=world, rank=rank, device=self.local_rank, gemv_variant=args.variant, lda_pad=args.lda_pad,
+                      profile_gemv=self.profile_every)
+        box = {"s": None, "uid": None, "handle": None}
+        self.state["stage"] = "wire-up of transport " + transport
 
-        def stage(what, fn):
+        def stage(what, fn, bounded=True):
             ok = True
             try:
-                ok = fn() is not False
-            except Exception as e:                   # noqa: BLE001 -- any failure means "do not use this transport"
-                print("bench.py rank %d: transport %s unavailable (%s): %s" % (rank, transport, what, e),
-                      file=sys.stderr, flush=True)
+                ok = (call_with_timeout(fn, args.wireup_timeout, "%s/%s" % (transport, what)) if bounded else fn()) is not False
+            except BaseException as e:               # noqa: BLE001 -- any failure means "do not use this transport"
+                self.log("transport %s unavailable (%s): %s" % (transport, what, e))
+                self.notes.append("%s dropped at '%s' on rank %d: %s" % (transport, what, rank, str(e)[:200]))
                 ok = False
-            return all_ok(ok)
+            return self.all_ok(ok)
 
         def give_up():
             if box["s"] is not None:
-                box["s"].close()
+                try:
+                    box["s"].close()
+                except Exception:                    # noqa: BLE001
+                    pass
             return None
 
         if transport == "self":
             def create():
                 box["s"] = pkg.CGSolver(comm_mode=pkg.COMM_SELF, **common)
-            if not stage("create", create):
+            if not stage("create", create, bounded=False):
                 return give_up()
         elif transport == "rccl":
             # replaces mpirun's wire-up (MPI_Init, cg_main.cc:15-20): every rank gets rank 0's RCCL id
@@ -211,7 +304,7 @@ def main():
                 box["uid"] = pkg.comm_unique_id() if rank == 0 else None
             if not stage("unique id", make_id):
                 return give_up()
-            uid = broadcast_bytes(dist, box["uid"], pkg.cgx.UNIQUE_ID_BYTES, ctl)
+            uid = broadcast_bytes(dist, box["uid"], pkg.cgx.UNIQUE_ID_BYTES, self.ctl)
 
             def create():
                 box["s"] = pkg.CGSolver(comm_mode=pkg.COMM_RCCL, unique_id=uid, **common)
@@ -223,7 +316,8 @@ def main():
                 box["handle"] = box["s"].p2p_export()
             if not stage("mailbox allocation", create):
                 return give_up()
-            mine = torch.tensor(list(box["handle"]), dtype=torch.uint8, device=ctl)
+            torch = self.torch
+            mine = torch.tensor(list(box["handle"]), dtype=torch.uint8, device=self.ctl)
             allh = [torch.zeros_like(mine) for _ in range(world)]
             dist.all_gather(allh, mine)              # every rank's mailbox handle to every rank
 
@@ -242,13 +336,15 @@ def main():
         def problem():
             box["s"].generate_lap2d_matrix(n)
             box["s"].init_source_term(1.0 / n)
-        if not stage("problem set-up", problem):
+        if not stage("problem set-up", problem, bounded=False):
             return give_up()
         return box["s"]
 
-    def run(s, warmup, steps):
-        """W warm-up + K timed loop bodies on solver s.  Returns (elapsed, result) or None.  Every rank makes
+    # ---- the measurement ------------------------------------------------------------------------------
+    def run(self, s, warmup, steps):
+        """W warm-up + K timed loop bodies on solver s.  Returns (elapsed, result, samples) or None.  Every rank makes
         the same sequence of torch.distributed calls whatever fails locally, so a failure cannot desynchronise."""
+        np, torch, dist, n = self.np, self.torch, self.dist, self.n
         ok = True
         x = np.zeros(n)
         try:
@@ -257,157 +353,302 @@ def main():
             s.solve_begin(x)
             s.solve_steps(warmup)
         except Exception as e:             # noqa: BLE001
-            print("bench.py rank %d: warm-up failed: %s" % (rank, e), file=sys.stderr, flush=True)
+            self.log("warm-up failed: %s" % e)
             ok = False
-        if not all_ok(ok):
+        if not self.all_ok(ok):
             return None
-        sync()
+        self.sync()
         t0 = time.perf_counter()
         try:
             s.solve_steps(steps)           # enqueues K loop bodies and synchronises the library's stream
         except Exception as e:             # noqa: BLE001
-            print("bench.py rank %d: timed steps failed: %s" % (rank, e), file=sys.stderr, flush=True)
+            self.log("timed steps failed: %s" % e)
             ok = False
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         elapsed = time.perf_counter() - t0
-        res = None
+        res, samples = None, None
         try:
+            samples = s.gemv_samples() if self.profile_every else np.zeros(0)
             res = s.solve_end(x)
         except Exception as e:             # noqa: BLE001
-            print("bench.py rank %d: solve_end failed: %s" % (rank, e), file=sys.stderr, flush=True)
+            self.log("solve_end failed: %s" % e)
             ok = False
         if ok and dist is not None:
             # every rank must have reached bit-identical scalars (a stale or torn exchange would break this)
-            mine = torch.tensor([res["iterations"], res["residual_prev"], res["x_norm"]], dtype=torch.float64, device=ctl)
-            allv = [torch.zeros_like(mine) for _ in range(world)]
-            dist.all_gather(allv, mine)
-            if not all(torch.equal(allv[0], v) for v in allv) or not math.isfinite(res["residual_prev"]):
-                print("bench.py rank %d: ranks disagree on the result" % rank, file=sys.stderr, flush=True)
+            allv = self.gather_rows([res["iterations"], res["residual_prev"], res["x_norm"]])
+            if not all(v == allv[0] for v in allv) or not math.isfinite(res["residual_prev"]):
+                self.log("ranks disagree on the result")
                 ok = False
         elif dist is not None:
-            dummy = torch.zeros(3, dtype=torch.float64, device=ctl)
-            dist.all_gather([torch.zeros_like(dummy) for _ in range(world)], dummy)
-        if not all_ok(ok):
+            self.gather_rows([0.0, 0.0, 0.0])
+        if not self.all_ok(ok):
             return None
-        return elapsed, res
+        return elapsed, res, samples
 
-    def prewarm(s):
-        """Untimed: about half a second of the same iteration, so that the timed region runs at settled clocks
-        (the first ~0.2 s after start-up run 5-10 % slower; with 8 GPUs the whole default run is < 0.2 s).
-        The step count is computed, not measured, so every rank does the same number of exchanges."""
-        est = 8.0 * n * n / max(world, 1) / 6.5e12 + 25e-6
-        iters = max(50, min(20000, int(0.5 / est)))
-        return run(s, 0, iters) is not None
+    def prewarm(self, s, tname):
+        """Untimed: the same iteration in windows of about a quarter of a second until two successive windows take
+        the same time to 0.4 % (clocks settled; a box that has just been powered up needs longer than a warm one), at
+        least two and at most eight windows.  The window length is computed, not measured, and the stop decision is
+        taken on the max over ranks, so every rank does the same number of exchanges."""
+        est = 8.0 * self.n * self.n / max(self.world, 1) / 6.5e12 + 25e-6
+        iters = max(25, min(10000, int(0.25 / est)))
+        prev, total = None, 0
+        for _ in range(8):
+            out = self.run(s, 0, iters)
+            if out is None:
+                return False
+            t = self.max_over_ranks(out[0])
+            total += iters
+            if prev is not None and abs(t - prev) <= 0.004 * t:
+                break
+            prev = t
+        self.prewarm_iterations[tname] = total
+        return True
 
-    def max_over_ranks(v):
-        if dist is None:
-            return v
-        t = torch.tensor([v], dtype=torch.float64, device=ctl)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        return float(t.item())
+    def max_over_ranks(self, v):
+        return max(r[0] for r in self.gather_rows([v]))
 
-    if not use_comm:
-        order = ["self"]
-    elif args.transport == "auto":
-        order = ["p2p", "p2p-sep", "rccl"]
-    else:
-        order = [args.transport]
-    # Build every candidate transport that works on this node; with more than one, a short calibration run
-    # (same workload, 60 iterations) decides which one carries the timed run.  All decisions are taken on
-    # rank-reduced values, so every rank takes the same branch.
-    solvers = {}
-    for tname in order:
-        cand = make_solver(tname)
-        if cand is not None:
-            solvers[tname] = cand
-    for tname, cand in list(solvers.items()):
-        if not prewarm(cand):
-            cand.close()
-            del solvers[tname]
-    calib = {}
-    if len(solvers) > 1:
+    def solve_window(self, s, steps):
+        """The same K iterations through the reference's own timing window: ONE solve() call, timed inside the library
+        from its first to its last statement (cg_main.cc:53-55 times all of CGSolver::solve: set-up, the initial
+        residual GEMV, the loop, the gather of x and the DEBUG verification GEMV).  Untimed by bench.py's own clock."""
+        np = self.np
+        ok, res = True, None
+        x = np.zeros(self.n)
+        try:
+            s.set_max_iter(steps)
+            s.tolerance(0.0)
+            res = s.solve(x)
+        except Exception as e:             # noqa: BLE001
+            self.log("solve-window run failed: %s" % e)
+            ok = False
+        if not self.all_ok(ok):
+            return None
+        secs = self.max_over_ranks(res["seconds_solve"])
+        return {"iterations": res["iterations"], "seconds_solve": secs, "iterations_per_s": res["iterations"] / secs,
+                "what": "one cgx_solve() of K iterations, the reference's window cg_main.cc:53-55 (setup + initial "
+                        "GEMV + loop + gather of x + verification GEMV), max over ranks"}
+
+    def measure(self):
+        args, world, rank, n, pkg = self.args, self.world, self.rank, self.n, self.pkg
+        if not self.use_comm:
+            order = ["self"]
+        elif args.transport == "auto":
+            order = ["p2p", "p2p-sep", "rccl"]
+        else:
+            order = [args.transport]
+        # Build every candidate transport that works on this node; with more than one, a short calibration run
+        # (same workload, 60 iterations) decides which one carries the timed run.  All decisions are taken on
+        # rank-reduced values, so every rank takes the same branch.
+        solvers = {}
+        for tname in order:
+            cand = self.make_solver(tname)
+            if cand is not None:
+                solvers[tname] = cand
+        self.state["stage"] = "pre-warm"
         for tname, cand in list(solvers.items()):
-            c = run(cand, 30, 60)
-            if c is None:
+            if not self.prewarm(cand, tname):
+                self.notes.append("%s dropped: pre-warm run failed" % tname)
                 cand.close()
                 del solvers[tname]
-            else:
-                calib[tname] = max_over_ranks(c[0]) / 60 * 1e3
-    out, transport, solver = None, None, None
-    for tname in sorted(solvers, key=lambda t: calib.get(t, 0.0)):
-        out = run(solvers[tname], args.warmup, args.steps)
-        if out is not None:
-            transport, solver = tname, solvers[tname]
-            break
-    if out is None:
-        sys.exit("bench.py: no transport produced a result")
-    for tname, cand in solvers.items():
-        if cand is not solver:
-            cand.close()
-    elapsed, res = out
+        calib = {}
+        if len(solvers) > 1:
+            self.state["stage"] = "transport calibration"
+            for tname, cand in list(solvers.items()):
+                c = self.run(cand, 30, 60)
+                if c is None:
+                    self.notes.append("%s dropped: calibration run failed" % tname)
+                    cand.close()
+                    del solvers[tname]
+                else:
+                    calib[tname] = self.max_over_ranks(c[0]) / 60 * 1e3
+        self.state["stage"] = "timed run"
+        out, transport, solver = None, None, None
+        for tname in sorted(solvers, key=lambda t: calib.get(t, 0.0)):
+            out = self.run(solvers[tname], args.warmup, args.steps)
+            if out is not None:
+                transport, solver = tname, solvers[tname]
+                break
+            self.notes.append("%s dropped: timed run failed" % tname)
+        if out is None:
+            raise RuntimeError("no transport produced a result (%s)" % ("; ".join(self.notes) or "none could be built"))
+        for tname, cand in solvers.items():
+            if cand is not solver:
+                cand.close()
+        self.solver = solver
+        elapsed, res, samples = out
+        elapsed = self.max_over_ranks(elapsed)
 
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        g_ms = torch.tensor([res["gemv_ms_avg"]], dtype=torch.float64, device=ctl)
-        dist.all_reduce(g_ms, op=dist.ReduceOp.MAX)
-        gemv_ms = float(g_ms.item())
-    else:
-        gemv_ms = res["gemv_ms_avg"]
+        # K1 statistics of every rank: [rows, samples, discarded, min, median, mean, max] (ms)
+        starts, counts = pkg.partition(n, world)
+        my_rows = counts[rank]
+        k1_rows = self.gather_rows([my_rows, res["gemv_launches"], res["gemv_discarded"], res["gemv_ms_min"],
+                                    res["gemv_ms_median"], res["gemv_ms_avg"], res["gemv_ms_max"]])
+        info = solver.comm_info()
+        devices = self.gather_strings(info["device_id"])
+        wired = self.gather_rows([info["ranks_wired"], info["rank_seen"]])
 
-    if rank == 0:
-        rows0 = pkg.partition(n, world)[1][0]
-        gemv_bytes = 8.0 * (rows0 * n + n + rows0)            # SURVEY.md section 8(d): A rows once + p + Ap
-        ach = gemv_bytes / (gemv_ms * 1e-3) / 1e9 if gemv_ms > 0 else None
-        line = {
-            "metric": "cg_iterations_per_sec",
-            "value": args.steps / elapsed,
-            "unit": "iterations/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": args.mode,
-            "vs_baseline": None,           # the reference publishes seconds only, nothing at this N (BASELINE.md section 1)
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {
-                "workload": "generate_lap2d_matrix N=%d, init_source_term(1/N), fixed-iteration dense fp64 CG "
-                            "(BASELINE.json configs[%d])" % (n, 4 if args.mode == "weak" else (2 if world == 1 else 3)),
-                "n": n, "rows_per_gpu": rows0, "parallelism": "rowblock%d" % world,
-                "collectives": {"self": "none",
-                                "rccl": "1 x ncclAllGather per iteration ([Ap slice | p.Ap partials])",
-                                "p2p": "1 exchange per iteration over IPC/xGMI mailboxes, folded into K3 ([Ap slice | p.Ap])",
-                                "p2p-sep": "1 mailbox all-gather kernel per iteration over IPC/xGMI ([Ap slice | p.Ap])"}[transport],
-                "transport": transport,
-                "transport_calibration_ms_per_iteration": calib or None,
-                "k1_variant": args.variant,
-            },
-            "roofline": {
-                "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (ach / HBM_PEAK_GBS) if ach else None,
-                "traffic": pmc_traffic(n, world),
-                "kernel": "k_gemv (K1, A.p of this rank's row block)", "bytes_per_launch": gemv_bytes,
-                "avg_launch_ms": gemv_ms, "launches_timed": res["gemv_launches"],
-            },
-            "aggregate_gemv_GBs": (ach * world) if ach else None,
-            "whole_iteration_GBs_per_gpu": 8.0 * (rows0 * n + n + 14 * rows0) / (elapsed / args.steps) / 1e9,
-            "residual_after_run": res["residual_prev"],
-            "iterations_done": res["iterations"],
+        self.state["stage"] = "solve-window run"
+        window = None if args.no_solve_window else self.solve_window(solver, args.steps)
+
+        if rank != 0:
+            return None
+        ms_per_step = elapsed / args.steps * 1e3
+        per_rank = []
+        for q, (rows_q, cnt, disc, mn, med, avg, mx) in enumerate(k1_rows):
+            bytes_q = 8.0 * (rows_q * n + n + rows_q)          # SURVEY.md section 8(d): A rows once + p + Ap
+            per_rank.append({"rank": q, "rows": int(rows_q), "bytes_per_launch": bytes_q, "launches_timed": int(cnt),
+                             "launches_discarded": int(disc), "min_ms": mn, "median_ms": med, "mean_ms": avg, "max_ms": mx,
+                             "GBs": (bytes_q / (med * 1e-3) / 1e9) if med > 0 else None})
+        timed_ranks = [r for r in per_rank if r["GBs"]]
+        lim = min(timed_ranks, key=lambda r: r["GBs"]) if timed_ranks else None   # the rank furthest below the roofline
+        slowest = max(timed_ranks, key=lambda r: r["median_ms"]) if timed_ranks else None
+        roof = {
+            "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
+            "traffic": pmc_traffic(n, world),
+            "traffic_source": "committed rocprofv3 --pmc pass, %s (FETCH_SIZE x2 + WRITE_SIZE per the guide's gfx950 "
+                              "correction); NOT a counter of this run" % TRAFFIC_FILE,
+            "kernel": "k_gemv (K1, A.p of this rank's row block)",
+            "timing": "HIP events bound to the K1 dispatch (kernel begin/end) on the library's stream, every %s launch "
+                      "of the timed region, median; the first launch after the sync is not sampled"
+                      % ("" if self.profile_every == 1 else "%d-th" % self.profile_every),
         }
+        if lim is not None:
+            ok = lim["median_ms"] <= ms_per_step          # a kernel that runs once per step cannot outlast the step
+            roof.update({
+                "bytes_per_launch": lim["bytes_per_launch"], "median_launch_ms": lim["median_ms"],
+                "avg_launch_ms": lim["mean_ms"], "min_launch_ms": lim["min_ms"], "max_launch_ms": lim["max_ms"],
+                "launches_timed": lim["launches_timed"], "launches_discarded": lim["launches_discarded"],
+                "rank": lim["rank"], "consistency": "ok" if ok else "violated",
+            })
+            if ok:
+                roof["achieved"] = lim["GBs"]
+                roof["frac"] = lim["GBs"] / HBM_PEAK_GBS
+            else:
+                roof["note"] = ("median_launch_ms exceeds ms_per_step: the K1 timing is not trustworthy for this run, "
+                                "no fraction is reported")
+        line = base_line(args, world, n)
+        rows0 = counts[0]
+        line.update({"value": args.steps / elapsed, "ms_per_step": ms_per_step})
+        line["config"].update({
+            "rows_per_gpu": rows0,
+            "collectives": {"self": "none",
+                            "rccl": "1 x ncclAllGather per iteration ([Ap slice | p.Ap partials])",
+                            "p2p": "1 exchange per iteration over IPC/xGMI mailboxes, folded into K3 ([Ap slice | p.Ap])",
+                            "p2p-sep": "1 mailbox all-gather kernel per iteration over IPC/xGMI ([Ap slice | p.Ap])"}[transport],
+            "transport": transport,
+            "transport_calibration_ms_per_iteration": calib or None,
+            "transport_notes": self.notes or None,
+            "k1_variant": args.variant,
+            "prewarm_iterations": self.prewarm_iterations.get(transport),   # untimed, before the W warm-up steps
+            # what the transports really span (from the transports, not from the flags)
+            "process_group_ranks": self.dist.get_world_size() if self.dist is not None else 1,
+            "rccl_nranks": int(wired[0][0]) if transport == "rccl" else None,      # ncclCommCount of the library's communicator
+            "transport_ranks_wired": [int(w[0]) for w in wired],
+            "ranks_seen": len(k1_rows),                                            # ranks whose results were compared bit for bit
+            "distinct_gpus": len(set(devices)), "gpu_pci_ids": devices,
+        })
+        line["roofline"] = roof
+        if world > 1:
+            line["k1_per_rank"] = per_rank
+            line["k1_slowest_rank"] = slowest["rank"] if slowest else None
+        line["aggregate_gemv_GBs"] = sum(r["GBs"] for r in timed_ranks) if timed_ranks else None
+        line["whole_iteration_GBs_per_gpu"] = 8.0 * (rows0 * n + n + 14 * rows0) / (elapsed / args.steps) / 1e9
+        if 0 < len(samples) <= 64:
+            line["k1_samples_ms"] = [round(float(v), 5) for v in samples]      # rank 0's launches, launch order
+        line["residual_after_run"] = res["residual_prev"]
+        line["iterations_done"] = res["iterations"]
+        if window is not None:
+            line["solve_window_iterations_per_s"] = window["iterations_per_s"]
+            line["solve_window"] = window
         if world == 1 and not args.no_cpu_baseline:
+            self.state["stage"] = "cpu baseline"
             line["cpu_baseline"] = cpu_baseline(n, args.cpu_baseline_iters)
-        sys.stdout.flush()
-        os.write(json_fd, (json.dumps(line) + "\n").encode())
+        return line
 
-    solver.close()
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    def teardown(self):
+        if getattr(self, "solver", None) is not None:
+            self.solver.close()
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def main():
+    args = parse_args()
+    # stdout carries the ONE JSON line and nothing else: whatever the libraries print on fd 1 while the run is
+    # going (RCCL's version banner, for one) is sent to stderr instead.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    state = {"stage": "start", "printed": False}
+    lock = threading.Lock()
+
+    def emit(line):
+        """Rank 0 prints exactly one line, whoever gets here first (main thread, watchdog or signal handler)."""
+        with lock:
+            if rank != 0 or state["printed"]:
+                return
+            state["printed"] = True
+            os.write(json_fd, (json.dumps(line) + "\n").encode())
+
+    def failure_line(kind, message):
+        line = base_line(args, max(world, args.gpus), problem_size(args, max(world, args.gpus)))
+        line["error"] = {"kind": kind, "stage": state["stage"], "message": str(message)[:2000]}
+        return line
+
+    def on_watchdog():
+        printed = state["printed"]
+        emit(failure_line("watchdog", "no result after %.0f s" % args.watchdog))
+        print("bench.py rank %d: watchdog expired in stage '%s'" % (rank, state["stage"]), file=sys.stderr, flush=True)
+        os._exit(0 if printed else 3)
+
+    def wait_for_sigterm():
+        # SIGTERM is what the launcher sends when another rank died.  A Python-level handler would only run once the
+        # main thread is back from whatever C call it is blocked in, so a dedicated thread waits for the signal.
+        signum = signal.sigwait({signal.SIGTERM})
+        emit(failure_line("signal", "received signal %d (the launcher stops this rank: another rank failed?)" % signum))
+        os._exit(4)
+
+    signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM})   # before any thread exists: every thread inherits the mask
+    threading.Thread(target=wait_for_sigterm, daemon=True, name="bench-sigterm").start()
+    dog = threading.Timer(args.watchdog, on_watchdog)
+    dog.daemon = True
+    dog.start()
+
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            emit(failure_line("launch", "bench.py --gpus %d must be launched with torch.distributed.run "
+                                        "--nproc-per-node %d" % (args.gpus, args.gpus)))
+            print("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
+                  % (args.gpus, args.gpus), file=sys.stderr)
+            os._exit(2)
+        args.gpus = world
+
+    b = Bench(args, world, rank, local_rank, state)
+    rc = 0
+    try:
+        b.init()
+        line = b.measure()
+        if rank == 0:
+            emit(line)
+        state["stage"] = "teardown"
+        b.teardown()
+    except BaseException as e:               # noqa: BLE001 -- rank 0 must still print its line
+        traceback.print_exc(file=sys.stderr)
+        emit(failure_line(type(e).__name__, e))
+        rc = 1
+    sys.stderr.flush()
+    # Abandoned helper threads (a wire-up stage that timed out) must not keep the process alive, hence os._exit on
+    # every path but the clean one; the clean one leaves normally so that a profiler's exit handlers still run.
+    if rc != 0 or any(t.name.startswith("bench-") and t.name != "bench-sigterm" for t in threading.enumerate()):
+        os._exit(rc)
+    sys.exit(0)
 
 
 if __name__ == "__main__":

@@ -21,11 +21,11 @@ MAX_DIAGONALS = 64
 
 EXPORTS = [
     "cgx_config_init", "cgx_comm_unique_id", "cgx_create", "cgx_destroy", "cgx_last_error", "cgx_status_string",
-    "cgx_p2p_export", "cgx_p2p_import", "cgx_p2p_selftest",
+    "cgx_get_comm_info", "cgx_p2p_export", "cgx_p2p_import", "cgx_p2p_selftest",
     "cgx_partition", "cgx_generate_lap2d_matrix", "cgx_set_matrix_dense", "cgx_read_matrix",
     "cgx_init_source_term", "cgx_set_source_term", "cgx_set_max_iter", "cgx_set_tolerance", "cgx_get_size",
     "cgx_get_matrix_format",
-    "cgx_solve", "cgx_solve_begin", "cgx_solve_steps", "cgx_solve_end",
+    "cgx_solve", "cgx_solve_begin", "cgx_solve_steps", "cgx_solve_end", "cgx_get_gemv_samples",
     "cgx_probe_gemv", "cgx_probe_time_gemv", "cgx_probe_vector_ops", "cgx_probe_get_matrix_rows",
 ]
 
@@ -36,7 +36,8 @@ class Config(C.Structure):
         ("nranks", C.c_int), ("unique_id", C.c_ubyte * UNIQUE_ID_BYTES), ("gemv_variant", C.c_int),
         ("lda_pad", C.c_int), ("check_every", C.c_int), ("profile_gemv", C.c_int), ("reserved0", C.c_int),
         ("p2p_mailbox_kib", C.c_int), ("p2p_timeout_ms", C.c_int), ("p2p_separate_exchange", C.c_int),
-        ("matrix_format", C.c_int), ("reserved", C.c_int * 4),
+        ("matrix_format", C.c_int), ("profile_first", C.c_int), ("profile_markers", C.c_int),
+        ("reserved", C.c_int * 2),
     ]
 
 
@@ -46,7 +47,8 @@ class Result(C.Structure):
         ("residual_last", C.c_double), ("x_norm", C.c_double), ("rel_residual", C.c_double),
         ("seconds_solve", C.c_double), ("seconds_loop", C.c_double), ("gemv_ms_avg", C.c_double),
         ("gemv_ms_min", C.c_double), ("gemv_launches", C.c_longlong), ("gemv_bytes", C.c_double),
-        ("reserved", C.c_double * 4),
+        ("gemv_ms_median", C.c_double), ("gemv_ms_max", C.c_double), ("gemv_discarded", C.c_longlong),
+        ("reserved", C.c_double * 1),
     ]
 
     def as_dict(self):
@@ -89,6 +91,7 @@ def lib():
         L.cgx_last_error.restype = C.c_char_p
         L.cgx_status_string.argtypes = [C.c_int]
         L.cgx_status_string.restype = C.c_char_p
+        L.cgx_get_comm_info.argtypes = [vp, ip, ip, ip, C.c_char_p]
         L.cgx_p2p_export.argtypes = [vp, C.POINTER(C.c_ubyte)]
         L.cgx_p2p_import.argtypes = [vp, C.POINTER(C.c_ubyte)]
         L.cgx_p2p_selftest.argtypes = [vp, C.c_int, ip]
@@ -106,6 +109,7 @@ def lib():
         L.cgx_solve_begin.argtypes = [vp, dp]
         L.cgx_solve_steps.argtypes = [vp, C.c_int, ip]
         L.cgx_solve_end.argtypes = [vp, dp, C.POINTER(Result)]
+        L.cgx_get_gemv_samples.argtypes = [vp, dp, C.c_int, ip]
         L.cgx_probe_gemv.argtypes = [vp, dp, dp, dp]
         L.cgx_probe_time_gemv.argtypes = [vp, C.c_int, dp]
         L.cgx_probe_vector_ops.argtypes = [vp, C.c_int, C.c_double, C.c_double, dp, dp, dp, dp, dp]
@@ -149,7 +153,8 @@ class CGSolver:
 
     def __init__(self, comm_mode=COMM_SELF, nranks=1, rank=0, device=0, unique_id=None, gemv_variant=0,
                  lda_pad=-1, check_every=0, profile_gemv=False, p2p_timeout_ms=0, p2p_mailbox_kib=0,
-                 p2p_separate_exchange=False, matrix_format=MATRIX_DENSE):
+                 p2p_separate_exchange=False, matrix_format=MATRIX_DENSE, profile_first=False,
+                 profile_markers=False):
         L = lib()
         cfg = Config()
         L.cgx_config_init(C.byref(cfg))
@@ -165,6 +170,8 @@ class CGSolver:
         cfg.p2p_mailbox_kib = p2p_mailbox_kib
         cfg.p2p_separate_exchange = 1 if p2p_separate_exchange else 0
         cfg.matrix_format = matrix_format
+        cfg.profile_first = 1 if profile_first else 0
+        cfg.profile_markers = 1 if profile_markers else 0
         if unique_id is not None:
             assert len(unique_id) == UNIQUE_ID_BYTES
             C.memmove(cfg.unique_id, bytes(unique_id), UNIQUE_ID_BYTES)
@@ -197,6 +204,14 @@ class CGSolver:
 
     def __exit__(self, *exc):
         self.close()
+
+    def comm_info(self):
+        """What the transport really spans: {'comm_mode', 'ranks_wired', 'rank_seen', 'device_id'} (cgx_get_comm_info)."""
+        mode, wired, seen = C.c_int(), C.c_int(), C.c_int()
+        dev = C.create_string_buffer(32)
+        self._check(lib().cgx_get_comm_info(self._h, C.byref(mode), C.byref(wired), C.byref(seen), dev))
+        return {"comm_mode": mode.value, "ranks_wired": wired.value, "rank_seen": seen.value,
+                "device_id": dev.value.decode(errors="replace")}
 
     # -- direct peer exchange wire-up (COMM_P2P) ------------------------------------------------------
     def p2p_export(self):
@@ -281,6 +296,15 @@ class CGSolver:
         xp = _dp(x) if x is not None else None
         self._check(lib().cgx_solve_end(self._h, xp, C.byref(res)))
         return res.as_dict()
+
+    def gemv_samples(self):
+        """K1 durations (ms) of the most recent solve_steps call, launch order (needs profile_gemv)."""
+        cnt = C.c_int()
+        self._check(lib().cgx_get_gemv_samples(self._h, None, 0, C.byref(cnt)))
+        out = np.zeros(cnt.value, dtype=np.float64)
+        if cnt.value:
+            self._check(lib().cgx_get_gemv_samples(self._h, _dp(out), cnt.value, C.byref(cnt)))
+        return out
 
     # -- kernel probes -------------------------------------------------------------------------------
     def probe_gemv(self, p):

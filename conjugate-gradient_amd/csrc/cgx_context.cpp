@@ -326,7 +326,7 @@ cgx_status cgx_create(cgx_ctx **out, const cgx_config *cfg_in)
         ctx->err = "hipStreamCreate failed";
         return bail(CGX_ERR_HIP);
     }
-    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_flags), 4 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
+    if (hipHostMalloc(reinterpret_cast<void **>(&ctx->h_flags), 8 * sizeof(int), hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->flag_ev[0], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->flag_ev[1], hipEventDisableTiming) != hipSuccess) {
         ctx->err = "pinned flag / event allocation failed";
@@ -365,6 +365,37 @@ cgx_status cgx_create(cgx_ctx **out, const cgx_config *cfg_in)
         if (cfg.nranks == 1) ctx->p2p_ready = true;
     }
     *out = ctx;
+    return CGX_OK;
+}
+
+cgx_status cgx_get_comm_info(cgx_ctx *ctx, int *comm_mode, int *ranks_wired, int *rank_seen, char *device_id)
+{
+    if (!ctx) return CGX_ERR_BAD_ARG;
+    int wired = 1, seen = ctx->cfg.rank;
+    switch (ctx->cfg.comm_mode) {
+    case CGX_COMM_RCCL:
+        if (!ctx->comm || !ctx->rccl) return fail(ctx, CGX_ERR_RCCL, "no communicator");
+        NCCL_TRY(ctx, ctx->rccl->CommCount(ctx->comm, &wired));
+        NCCL_TRY(ctx, ctx->rccl->CommUserRank(ctx->comm, &seen));
+        break;
+    case CGX_COMM_P2P:
+        wired = 0;
+        for (int q = 0; q < ctx->nranks; ++q)
+            if (ctx->mv.base[q] && (q == ctx->cfg.rank || ctx->p2p_ready)) ++wired;
+        break;
+    case CGX_COMM_LOOPBACK:
+        wired = ctx->nranks;
+        break;
+    default:
+        break;
+    }
+    if (comm_mode) *comm_mode = ctx->cfg.comm_mode;
+    if (ranks_wired) *ranks_wired = wired;
+    if (rank_seen) *rank_seen = seen;
+    if (device_id) {
+        device_id[0] = 0;
+        HIP_TRY(ctx, hipDeviceGetPCIBusId(device_id, 32, ctx->device));
+    }
     return CGX_OK;
 }
 

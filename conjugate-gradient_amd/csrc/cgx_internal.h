@@ -80,7 +80,7 @@ struct cgx_ctx {
     int k = 0;              // iterations enqueued so far
     bool done = false;
     int k_final = 0;
-    int *h_flags = nullptr;   // pinned: 2 slots x {done, k_final}
+    int *h_flags = nullptr;   // pinned: 2 polling slots + 1 for read_flags_sync, each {done, k_final}
     double *h_stage = nullptr;   // pinned, n doubles: x0 in / x out go through it, so that solve() never waits for the
                                  // runtime's first-use set-up of pageable copies (8 ms inside the reference's timing
                                  // window, measured); nullptr above 8 Mi rows (then the copies are direct)
@@ -90,9 +90,10 @@ struct cgx_ctx {
     // K1 timing
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
-    double gemv_ms_sum = 0, gemv_ms_min = 0;
-    long long gemv_launches = 0;
-    long long gemv_seq = 0;
+    double gemv_ms_sum = 0, gemv_ms_min = 0, gemv_ms_max = 0;
+    long long gemv_launches = 0, gemv_discarded = 0;
+    long long gemv_seq = 0;              // K1 launches of the current cgx_solve_steps call
+    std::vector<float> gemv_samples;     // their durations (ms), most recent steps call
 
     std::string err;
 };
@@ -146,5 +147,6 @@ cgx_status gather_scalars(cgx_ctx *ctx);
 cgx_status gather_segments(cgx_ctx *ctx, bool with_tail);
 cgx_status run_gemv_plain(cgx_ctx *ctx, Shard &s, const double *v_full);
 cgx_status check_p2p_error(cgx_ctx *ctx);
+void reset_gemv_stats(cgx_ctx *ctx);
 
 }  // namespace cgxi

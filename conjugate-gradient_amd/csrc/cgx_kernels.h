@@ -65,9 +65,12 @@ hipError_t launch_gemv_plain(const GemvPlan &plan, const double *A, long lda, in
 // K1, fused form = body of iteration k up to p.Ap (cg.cc:100-105) preceded by the tail of iteration k-1
 // (cg.cc:117-132): rsnew = sum of the gathered r.r; convergence test; beta; p_new = r + beta p_old computed
 // on the fly for every column (and stored once), Ap = A p_new, partials[wg] = the workgroup's part of p_new_local . Ap.
+// e_start / e_stop (both or neither): bound to the dispatch itself (hipExtLaunchKernel), so their difference is the
+// kernel's own begin -> end as rocprofv3 sees it, with no marker packets on the stream.
 hipError_t launch_gemv_fused(const GemvPlan &plan, const double *A, long lda, int rows, int row0,
                              const double *p_old, double *p_new, SegView seg, double *Ap, double *partials,
-                             Scalars *sc, int k, double tol, hipStream_t s);
+                             Scalars *sc, int k, double tol, hipStream_t s, hipEvent_t e_start = nullptr,
+                             hipEvent_t e_stop = nullptr);
 
 // K3: p.Ap = fixed-order sum over all ranks q of the tail_count doubles at tail_off of segment q's tail;
 // alpha = rsold / max(p.Ap, rsold*1e-14); x_sub += alpha p_sub (own rows); r -= alpha Ap for ALL n rows (r is
@@ -130,7 +133,8 @@ hipError_t launch_spmv_dia_plain(const GemvPlan &plan, const DiaView &dv, int ro
                                  double *Ap, double *partials, Scalars *sc, hipStream_t s);
 hipError_t launch_spmv_dia_fused(const GemvPlan &plan, const DiaView &dv, int rows, int row0, int n, long lda,
                                  const double *p_old, double *p_new, SegView seg, double *Ap, double *partials,
-                                 Scalars *sc, int k, double tol, hipStream_t s);
+                                 Scalars *sc, int k, double tol, hipStream_t s, hipEvent_t e_start = nullptr,
+                                 hipEvent_t e_stop = nullptr);
 // generate_lap2d_matrix (cg.cc:159-188) straight into banded storage; dv.off must be lap2d_offsets(size).
 int lap2d_offsets(int size, int *off /* >= 5 */);
 hipError_t launch_dia_generate_lap2d(double *vals, const DiaView &dv, int size, int row0, int rows, hipStream_t s);

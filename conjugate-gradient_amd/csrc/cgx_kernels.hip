@@ -29,6 +29,8 @@
 // every scalar on the device.
 #include "cgx_kernels.h"
 
+#include <hip/hip_ext.h>
+
 namespace cgx {
 
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -1103,17 +1105,18 @@ struct GemvArgs {
     Scalars *sc;
     int k;
     double tol;
+    hipEvent_t e0 = nullptr, e1 = nullptr;   // optional: bound to the dispatch (kernel begin / end)
 };
 
 template <int R, int U, int MODE>
 hipError_t launch_shape(const GemvPlan &pl, const GemvArgs &g, hipStream_t s)
 {
     if (pl.variant == 2)
-        hipLaunchKernelGGL((k_gemv_ldsp<R, U, 4, MODE>), dim3(pl.grid), dim3(256), 0, s, g.A, g.lda, g.rows, g.row0, g.v,
-                           g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol);
+        hipExtLaunchKernelGGL((k_gemv_ldsp<R, U, 4, MODE>), dim3(pl.grid), dim3(256), 0, s, g.e0, g.e1, 0, g.A, g.lda, g.rows,
+                              g.row0, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol);
     else
-        hipLaunchKernelGGL((k_gemv_colsplit<R, U, 4, MODE>), dim3(pl.grid), dim3(256), 0, s, g.A, g.lda, g.rows, g.row0,
-                           g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol);
+        hipExtLaunchKernelGGL((k_gemv_colsplit<R, U, 4, MODE>), dim3(pl.grid), dim3(256), 0, s, g.e0, g.e1, 0, g.A, g.lda,
+                              g.rows, g.row0, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol);
     return hipGetLastError();
 }
 
@@ -1145,9 +1148,9 @@ hipError_t launch_gemv_plain(const GemvPlan &pl, const double *A, long lda, int 
 
 hipError_t launch_gemv_fused(const GemvPlan &pl, const double *A, long lda, int rows, int row0, const double *p_old,
                              double *p_new, SegView seg, double *Ap, double *partials, Scalars *sc, int k, double tol,
-                             hipStream_t s)
+                             hipStream_t s, hipEvent_t e_start, hipEvent_t e_stop)
 {
-    GemvArgs g{A, lda, rows, row0, p_old, p_new, seg, Ap, partials, sc, k, tol};
+    GemvArgs g{A, lda, rows, row0, p_old, p_new, seg, Ap, partials, sc, k, tol, e_start, e_stop};
     return dispatch_gemv<kFusedSingle>(pl, g, s);
 }
 
@@ -1195,13 +1198,14 @@ struct DiaArgs {
     Scalars *sc;
     int k;
     double tol;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
 };
 
 template <int MODE, int CH>
 hipError_t launch_dia_chunk(const GemvPlan &pl, const DiaArgs &g, hipStream_t s)
 {
-    hipLaunchKernelGGL((k_spmv_dia<MODE, CH>), dim3(pl.grid), dim3(256), 0, s, g.dv, g.rows, g.row0, g.n, g.lda, g.v, g.p_new,
-                       g.sv, g.Ap, g.partials, g.sc, g.k, g.tol);
+    hipExtLaunchKernelGGL((k_spmv_dia<MODE, CH>), dim3(pl.grid), dim3(256), 0, s, g.e0, g.e1, 0, g.dv, g.rows, g.row0, g.n,
+                          g.lda, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol);
     return hipGetLastError();
 }
 
@@ -1243,9 +1247,10 @@ hipError_t launch_spmv_dia_plain(const GemvPlan &pl, const DiaView &dv, int rows
 
 hipError_t launch_spmv_dia_fused(const GemvPlan &pl, const DiaView &dv, int rows, int row0, int n, long lda,
                                  const double *p_old, double *p_new, SegView seg, double *Ap, double *partials,
-                                 Scalars *sc, int k, double tol, hipStream_t s)
+                                 Scalars *sc, int k, double tol, hipStream_t s, hipEvent_t e_start, hipEvent_t e_stop)
 {
-    return dispatch_dia<kFusedSingle>(pl, DiaArgs{dv, rows, row0, n, lda, p_old, p_new, seg, Ap, partials, sc, k, tol}, s);
+    return dispatch_dia<kFusedSingle>(
+        pl, DiaArgs{dv, rows, row0, n, lda, p_old, p_new, seg, Ap, partials, sc, k, tol, e_start, e_stop}, s);
 }
 
 int lap2d_offsets(int size, int *off)

@@ -50,7 +50,9 @@ const RcclApi *rccl_api(std::string *err)
                       bind(h, "ncclGroupStart", &a.GroupStart, &g_err) &&
                       bind(h, "ncclGroupEnd", &a.GroupEnd, &g_err) &&
                       bind(h, "ncclGetErrorString", &a.GetErrorString, &g_err) &&
-                      bind(h, "ncclGetVersion", &a.GetVersion, &g_err);
+                      bind(h, "ncclGetVersion", &a.GetVersion, &g_err) &&
+                      bind(h, "ncclCommCount", &a.CommCount, &g_err) &&
+                      bind(h, "ncclCommUserRank", &a.CommUserRank, &g_err);
             if (ok) g_api = a;
         }
     }

@@ -76,13 +76,18 @@ typedef struct cgx_config {
     int  gemv_variant;        /* 0 = library default; see DESIGN.md "K1 variants"           */
     int  lda_pad;             /* extra doubles added to the row pitch (-1 = library default)*/
     int  check_every;         /* iterations between host polls of the device `done` flag (0 = default) */
-    int  profile_gemv;        /* n > 0 = bracket every n-th K1 launch with HIP events (at most 2048 per cgx_solve_steps call) */
+    int  profile_gemv;        /* n > 0 = bracket every n-th K1 launch with HIP events (at most 2048 per cgx_solve_steps call);
+                                 the FIRST launch of a cgx_solve_steps call starts on a drained stream and is never
+                                 a sample unless profile_first is set (its event pair also spans the host's launch latency) */
     int  reserved0;           /* (was: hipGraph replay; not needed, the host is never the bottleneck of this loop) */
     int  p2p_mailbox_kib;     /* CGX_COMM_P2P: mailbox size in KiB (0 = 4096)               */
     int  p2p_timeout_ms;      /* CGX_COMM_P2P: bound of every in-kernel wait (0 = 5000)     */
     int  p2p_separate_exchange; /* CGX_COMM_P2P: 1 = exchange in its own kernel between K1 and K3 (default 0: folded into K3) */
     int  matrix_format;       /* cgx_matrix_format; 0 = dense = the reference's storage     */
-    int  reserved[4];
+    int  profile_first;       /* 1 = also sample the first K1 launch of every cgx_solve_steps call (diagnostics only) */
+    int  profile_markers;     /* 0 = the event pair is bound to the K1 dispatch itself (kernel begin/end, what rocprofv3 reports);
+                                 1 = hipEventRecord markers before and after it (diagnostics only: adds two packets per launch) */
+    int  reserved[2];
 } cgx_config;
 
 typedef struct cgx_result {
@@ -94,11 +99,14 @@ typedef struct cgx_result {
     double rel_residual;      /* ||Ax-b|| / ||b||  (cg.cc:145-150)                          */
     double seconds_solve;     /* reference timing window: all of solve() (cg_main.cc:53-55) */
     double seconds_loop;      /* the k-loop only                                            */
-    double gemv_ms_avg;       /* mean K1 launch duration (HIP events), 0 if not profiled    */
+    double gemv_ms_avg;       /* mean K1 launch duration (HIP events) over the most recent cgx_solve_steps call, 0 if not profiled */
     double gemv_ms_min;
-    long long gemv_launches;  /* K1 launches that were event-timed                          */
+    long long gemv_launches;  /* K1 launches that were event-timed (= samples behind avg / min / median / max) */
     double gemv_bytes;        /* algorithmic bytes of ONE K1 launch on this shard: 8*(rows*n + n + rows); banded: 8*(rows*ndiag + 2*rows) */
-    double reserved[4];
+    double gemv_ms_median;    /* median of the samples (SURVEY.md section 8d asks for the median) */
+    double gemv_ms_max;
+    long long gemv_discarded; /* launches deliberately not sampled although profiling was on: the first one after a drained stream */
+    double reserved[1];
 } cgx_result;
 
 typedef struct cgx_ctx cgx_ctx;
@@ -110,6 +118,15 @@ cgx_status  cgx_create(cgx_ctx **out, const cgx_config *cfg);
 cgx_status  cgx_destroy(cgx_ctx *ctx);
 const char *cgx_last_error(const cgx_ctx *ctx);               /* ctx may be NULL: error of the last failed cgx_create on this thread */
 const char *cgx_status_string(cgx_status s);
+
+/* What the transport of this context actually spans, for the benchmark record (replaces MPI_Comm_size / MPI_Comm_rank,
+ * cg.cc:50-51, as a CHECK: the values come from the transport, not from the configuration):
+ *   *ranks_wired  RCCL: ncclCommCount of the communicator; P2P: mailboxes mapped (own + peers) once imported;
+ *                 LOOPBACK: logical shards; SELF: 1
+ *   *rank_seen    RCCL: ncclCommUserRank; otherwise the configured rank
+ *   device_id     PCI bus id of the device this context drives ("0000:05:00.0"), so that a launcher can count the
+ *                 distinct GPUs behind its ranks; at least 32 bytes, may be NULL. */
+cgx_status  cgx_get_comm_info(cgx_ctx *ctx, int *comm_mode, int *ranks_wired, int *rank_seen, char *device_id);
 
 /* ---- CGX_COMM_P2P wire-up (replaces MPI_Init's job for the direct-xGMI transport) --------- */
 /* export: this rank's mailbox as an IPC handle.  import: all ranks' handles, rank order (nranks * 64 bytes),
@@ -162,6 +179,9 @@ cgx_status  cgx_solve(cgx_ctx *ctx, double *x, cgx_result *res);
 cgx_status  cgx_solve_begin(cgx_ctx *ctx, const double *x0);
 cgx_status  cgx_solve_steps(cgx_ctx *ctx, int nsteps, int *done_out);
 cgx_status  cgx_solve_end(cgx_ctx *ctx, double *x, cgx_result *res);
+/* The individual K1 durations (ms, HIP events on the library's stream) of the most recent cgx_solve_steps call, in
+ * launch order: at most `cap` are written, *count receives how many exist.  bench.py reports their median. */
+cgx_status  cgx_get_gemv_samples(const cgx_ctx *ctx, double *ms_out, int cap, int *count);
 
 /* ---- kernel probes (parity tests of the individual hot ops through the C ABI) ------------- */
 /* Ap = A_shard * p  (K1; cblas_dgemv at cg.cc:101-102) for every local shard; y receives the n
