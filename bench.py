@@ -390,16 +390,23 @@ class Bench:
     def prewarm(self, s, tname):
         """Untimed: the same iteration in windows of about a quarter of a second until two successive windows take
         the same time to 0.4 % (clocks settled; a box that has just been powered up needs longer than a warm one), at
-        least two and at most eight windows.  The window length is computed, not measured, and the stop decision is
-        taken on the max over ranks, so every rank does the same number of exchanges."""
+        least two and at most eight windows.  A window is cut into solves that stay below the iteration count at which
+        this matrix converges (~5.6 sqrt(N): with tol = 0 the recurrence would run on into 0/0).  All lengths are
+        computed, not measured, and the stop decision is taken on the max over ranks, so every rank does the same
+        number of exchanges."""
         est = 8.0 * self.n * self.n / max(self.world, 1) / 6.5e12 + 25e-6
         iters = max(25, min(10000, int(0.25 / est)))
+        chunk = max(10, min(iters, int(2.5 * math.sqrt(self.n))))
         prev, total = None, 0
         for _ in range(8):
-            out = self.run(s, 0, iters)
-            if out is None:
-                return False
-            t = self.max_over_ranks(out[0])
+            t, left = 0.0, iters
+            while left > 0:
+                k = min(chunk, left)
+                out = self.run(s, 0, k)
+                if out is None:
+                    return False
+                t += self.max_over_ranks(out[0])
+                left -= k
             total += iters
             if prev is not None and abs(t - prev) <= 0.004 * t:
                 break

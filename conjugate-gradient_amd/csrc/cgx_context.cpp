@@ -361,6 +361,7 @@ cgx_status cgx_create(cgx_ctx **out, const cgx_config *cfg_in)
         }
         ctx->mv.nranks = cfg.nranks;
         ctx->mv.rank = cfg.rank;
+        ctx->mv.acquire = cfg.p2p_no_acquire_fence ? 0 : 1;
         ctx->mv.base[cfg.rank] = ctx->mailbox;
         if (cfg.nranks == 1) ctx->p2p_ready = true;
     }

@@ -154,6 +154,8 @@ struct MailboxView {
     long data_off[kP2pChannels];         // byte offset of channel c's data area
     long slot_bytes[kP2pChannels];       // bytes per (parity, rank) slot
     int nranks, rank;
+    int acquire;                         // 1 = one system-scope acquire fence per workgroup behind the flag wait of
+                                         // k_update_xr_p2p (default); 0 only for the A/B of its cost (tools/p2p_one_rank.py)
 };
 
 // All-gather `count` doubles per rank: rank's own contribution is src; afterwards dst + q*dst_stride holds

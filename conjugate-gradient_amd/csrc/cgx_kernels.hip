@@ -992,8 +992,7 @@ __global__ __launch_bounds__(256) void k_update_xr_p2p(int n, int rows, int row0
         const unsigned long long *flag = reinterpret_cast<const unsigned long long *>(
             mv.base[me] + ((long)chan * kMaxRanks + tid) * kP2pFlagStride);
         const long long t0 = wall_clock64();
-        // relaxed polls (an acquire per poll would invalidate caches every time round); everything read after the
-        // barrier below is read with system-scope loads, which are served from memory, never from a stale line
+        // relaxed polls (an acquire per poll would invalidate caches every time round: 2-3x slower per hop)
         while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
             __builtin_amdgcn_s_sleep(4);
             if (wall_clock64() - t0 > timeout_ticks) {
@@ -1002,6 +1001,14 @@ __global__ __launch_bounds__(256) void k_update_xr_p2p(int n, int rows, int row0
                 break;
             }
         }
+    }
+    // ONE system-scope acquire per workgroup, by the wave that polled, drained before the barrier releases the others
+    // (the consumer form of the guide: relaxed polls -> one acquire -> s_waitcnt vmcnt(0) -> barrier -> loads).  Every
+    // load of handed-off bytes below is a system-scope load as well, so nothing here rests on one mechanism alone
+    // when the peer's stores arrive over xGMI instead of from a process on the same GPU.
+    if (mv.acquire && tid < 64) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (!__syncthreads_and(ok)) return;
     const unsigned long long *box = reinterpret_cast<const unsigned long long *>(mv.base[me] + mv.data_off[chan]);

@@ -87,7 +87,9 @@ typedef struct cgx_config {
     int  profile_first;       /* 1 = also sample the first K1 launch of every cgx_solve_steps call (diagnostics only) */
     int  profile_markers;     /* 0 = the event pair is bound to the K1 dispatch itself (kernel begin/end, what rocprofv3 reports);
                                  1 = hipEventRecord markers before and after it (diagnostics only: adds two packets per launch) */
-    int  reserved[2];
+    int  p2p_no_acquire_fence; /* diagnostics only: 1 = leave out the system-scope acquire fence behind the flag wait of the
+                                 fused update kernel (for measuring its cost); default 0 = fence on */
+    int  reserved[1];
 } cgx_config;
 
 typedef struct cgx_result {

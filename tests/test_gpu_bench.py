@@ -1,0 +1,127 @@
+"""bench.py on the GPU box: the line's contract on a short window (the driver runs --steps 20 --warmup 5), the
+launcher paths one GPU can rehearse (RCCL with one rank under torch.distributed.run; two ranks over the IPC mailboxes
+with a gloo control plane), and the promise that rank 0 prints a line whatever happens."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def one_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def torchrun(world, port, args, env=None, timeout=420):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), BENCH, "--gpus", str(world)] + args
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout,
+                          env=dict(os.environ, OMP_NUM_THREADS="1", MASTER_ADDR="127.0.0.1", **(env or {})))
+
+
+def test_bench_line_contract(gpu_pkg):
+    """One JSON line with the driver's keys plus roofline and cpu_baseline (small size so that it takes seconds)."""
+    r = subprocess.run([sys.executable, BENCH, "--steps", "30", "--warmup", "5", "--matrix-size", "4096",
+                        "--cpu-baseline-iters", "3"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = one_line(r.stdout)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 30 and d["warmup"] == 5 and d["dtype"] == "f64" and d["vs_baseline"] is None
+    assert d["value"] > 0 and abs(d["ms_per_step"] * d["value"] - 1000.0) < 1e-6 * 1000
+    assert "workload" in d["config"] and "model" not in d["config"]
+    rf = d["roofline"]
+    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and 0 < rf["frac"] < 1.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
+    assert "error" not in d
+
+
+def test_bench_short_window_statistics(gpu_pkg, oracle):
+    """The driver's window (20 timed steps after 5): every launch but the first is a sample, the median is what the
+    fraction is computed from, a K1 launch never outlasts the step it is part of, and the run is the reference's
+    recurrence (residual after 25 iterations against the oracle)."""
+    n = 8192
+    r = subprocess.run([sys.executable, BENCH, "--steps", "20", "--warmup", "5", "--matrix-size", str(n), "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = one_line(r.stdout)
+    rf = d["roofline"]
+    assert rf["launches_timed"] == 19 and rf["launches_discarded"] == 1 and rf["consistency"] == "ok"
+    assert rf["min_launch_ms"] <= rf["median_launch_ms"] <= rf["max_launch_ms"]
+    assert rf["median_launch_ms"] <= d["ms_per_step"]
+    assert abs(rf["achieved"] - rf["bytes_per_launch"] / (rf["median_launch_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]
+    assert rf["bytes_per_launch"] == 8.0 * (n * n + n + n)
+    assert "traffic_source" in rf and "NOT a counter of this run" in rf["traffic_source"]
+    assert len(d["k1_samples_ms"]) == 19
+    w = d["solve_window"]
+    assert w["iterations"] == 20 and abs(d["solve_window_iterations_per_s"] - 20 / w["seconds_solve"]) < 1e-9 * d["value"]
+    assert d["solve_window_iterations_per_s"] < d["value"]          # the window also holds set-up and two more GEMVs
+    assert d["iterations_done"] == 25
+    _, ro = oracle.solve_lap2d(n, 25, 0.0, 1)
+    assert abs(d["residual_after_run"] - ro["residual_prev"]) <= 1e-6 * ro["residual_prev"]
+    c = d["config"]
+    assert c["transport"] == "self" and c["ranks_seen"] == 1 and c["distinct_gpus"] == 1 and c["rccl_nranks"] is None
+
+
+def test_bench_rccl_one_rank_under_the_launcher(gpu_pkg, oracle):
+    """--transport rccl with one rank under torch.distributed.run: ncclGetUniqueId, the broadcast of the id,
+    ncclCommInitRank, one ncclAllGather per iteration on the library's stream, ncclCommCount in the line.  RCCL refuses
+    two ranks on one device, so one rank is what a one-GPU box can run of this path."""
+    n = 4096
+    r = torchrun(1, 29721, ["--steps", "30", "--warmup", "5", "--matrix-size", str(n), "--transport", "rccl", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    d = one_line(r.stdout)
+    c = d["config"]
+    assert c["transport"] == "rccl" and c["rccl_nranks"] == 1 and c["process_group_ranks"] == 1
+    assert c["transport_ranks_wired"] == [1] and c["ranks_seen"] == 1
+    assert d["value"] > 0 and d["iterations_done"] == 35 and d["roofline"]["consistency"] == "ok"
+    _, ro = oracle.solve_lap2d(n, 35, 0.0, 1)
+    assert abs(d["residual_after_run"] - ro["residual_prev"]) <= 1e-6 * ro["residual_prev"]
+
+
+def test_bench_two_ranks_over_the_mailboxes(gpu_pkg, oracle):
+    """bench.py's world > 1 flow end to end on one GPU: gloo control plane, both ranks on device 0, transport chosen
+    by the calibration among the two mailbox forms (RCCL drops out: two ranks on one device), per-rank K1 statistics."""
+    n = 4096
+    r = torchrun(2, 29722, ["--steps", "30", "--warmup", "5", "--matrix-size", str(n)], env={"CGX_BENCH_BACKEND": "gloo"})
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    d = one_line(r.stdout)
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["transport"] in ("p2p", "p2p-sep") and c["ranks_seen"] == 2
+    assert c["transport_ranks_wired"] == [2, 2] and c["distinct_gpus"] == 1 and c["process_group_ranks"] == 2
+    assert any("rccl" in note for note in c["transport_notes"])
+    assert [q["rank"] for q in d["k1_per_rank"]] == [0, 1] and [q["rows"] for q in d["k1_per_rank"]] == [2048, 2048]
+    assert d["k1_slowest_rank"] in (0, 1)
+    assert all(q["min_ms"] <= q["median_ms"] <= q["max_ms"] for q in d["k1_per_rank"])
+    _, ro = oracle.solve_lap2d(n, 35, 0.0, 2)
+    assert abs(d["residual_after_run"] - ro["residual_prev"]) <= 1e-6 * ro["residual_prev"]
+
+
+def test_bench_prints_a_failure_line_when_no_transport_works(gpu_pkg):
+    """Two ranks on one device with RCCL as the only allowed transport: ncclCommInitRank refuses, nothing can be timed,
+    and rank 0 still prints ONE line -- value null, an error object that says why."""
+    r = torchrun(2, 29723, ["--steps", "10", "--warmup", "2", "--matrix-size", "1024", "--transport", "rccl", "--wireup-timeout", "60"],
+                 env={"CGX_BENCH_BACKEND": "gloo"})
+    d = one_line(r.stdout)
+    assert d["value"] is None and d["n_gpus"] == 2 and d["steps"] == 10
+    assert "no transport produced a result" in d["error"]["message"] and "rccl" in d["error"]["message"]
+    assert r.returncode != 0
+
+
+def test_bench_watchdog_prints_a_failure_line(gpu_pkg):
+    """A run that cannot finish inside the watchdog still ends with one parseable line."""
+    r = subprocess.run([sys.executable, BENCH, "--steps", "500", "--warmup", "100", "--watchdog", "0.2", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=300)
+    d = one_line(r.stdout)
+    assert d["value"] is None and d["error"]["kind"] == "watchdog"
+    assert r.returncode == 3

@@ -528,27 +528,3 @@ def test_cgsolver_cli_both_forms(gpu_pkg, mtx_path, tmp_path):
     assert r.returncode == 0, r.stderr
     assert r.stdout.startswith("\t[STEP 100] residual = ")
     assert out3.read_text().strip().startswith("10000,2,")
-
-
-# ---- bench.py contract ----------------------------------------------------------------------------------------------
-def test_bench_line_contract(gpu_pkg):
-    """One JSON line with the driver's keys plus roofline and cpu_baseline (small size so that it takes seconds)."""
-    import json
-    import sys
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "30", "--warmup", "5", "--matrix-size", "4096",
-                        "--cpu-baseline-iters", "3"], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
-    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
-        assert k in d, k
-    assert d["n_gpus"] == 1 and d["steps"] == 30 and d["warmup"] == 5 and d["dtype"] == "f64" and d["vs_baseline"] is None
-    assert d["value"] > 0 and abs(d["ms_per_step"] * d["value"] - 1000.0) < 1e-6 * 1000
-    assert "workload" in d["config"] and "model" not in d["config"]
-    rf = d["roofline"]
-    assert rf["bound"] == "hbm" and rf["peak"] == 8000.0 and rf["unit"] == "GB/s" and 0 < rf["frac"] < 1.0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
-    cb = d["cpu_baseline"]
-    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
