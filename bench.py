@@ -8,8 +8,9 @@
 A "step" is one body of the CG loop (code/MPI/cg.cc:96-137 of the reference): one A.p GEMV over this
 rank's row block, two dot products, the x/r/p updates and the exchanges (here: ONE per iteration).  Inputs are synthetic and
 HBM-resident before the timed region: A = generate_lap2d_matrix(N) built on the device, b = init_source_term(1/N).
-W warmup steps, then exactly K steps between barrier + torch.cuda.synchronize(); MAX over ranks; rank 0
-prints ONE JSON line.  value = K / t for the whole job (every rank advances the same K iterations).
+W warmup steps, then exactly K steps between barrier + torch.cuda.synchronize() on both sides; every rank's clock runs from
+the leading barrier to the end of its own synchronize, the MAX over ranks (= when the last rank finished) is the job's
+time; rank 0 prints ONE JSON line.  value = K / t for the whole job (every rank advances the same K iterations).
 
 Extra objects in the line:
   roofline     -- K1 (the GEMV) against the 8 TB/s HBM peak: algorithmic bytes 8*(rows*N + N + rows) per launch
@@ -55,8 +56,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-gemv", action="store_true", help="do not time K1 with HIP events")
     ap.add_argument("--profile-every", type=int, default=0,
-                    help="event-time every n-th K1 launch (default: every launch when steps <= 64, so that a short "
-                         "window still gives >= 16 samples; else 4 on one GPU, 8 on several)")
+                    help="event-time every n-th K1 launch (default: when steps <= 64 every launch on one GPU, so that a "
+                         "short window still gives >= 16 samples, every 2nd on several; else 4 on one GPU, 8 on several)")
     ap.add_argument("--no-solve-window", action="store_true", help="skip the extra untimed solve() through the reference's window")
     ap.add_argument("--wireup-timeout", type=float, default=float(os.environ.get("CGX_BENCH_WIREUP_TIMEOUT", "90")),
                     help="seconds one transport's wire-up stage may take before that transport is dropped")
@@ -262,7 +263,9 @@ class Bench:
         elif args.profile_every:
             self.profile_every = args.profile_every
         else:
-            self.profile_every = 1 if args.steps <= 64 else (4 if world == 1 else 8)
+            # a timed dispatch costs ~5 us of stream time (measured): every launch on one GPU's 1.2 ms iteration,
+            # every second one where the iteration is a fraction of that
+            self.profile_every = (1 if world == 1 else 2) if args.steps <= 64 else (4 if world == 1 else 8)
 
     def make_solver(self, transport):
         """transport: 'self' | 'rccl' | 'p2p' | 'p2p-sep'.  Returns a ready solver or None (same answer on every rank).
@@ -365,9 +368,9 @@ class Bench:
             self.log("timed steps failed: %s" % e)
             ok = False
         torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0     # this rank's K steps are done; the MAX over ranks below is the job's time
         if dist is not None:
-            dist.barrier()
-        elapsed = time.perf_counter() - t0
+            dist.barrier()                     # closes the bracket; its own latency (a collective launch) is not CG work
         res, samples = None, None
         try:
             samples = s.gemv_samples() if self.profile_every else np.zeros(0)

@@ -27,6 +27,7 @@ EXPORTS = [
     "cgx_get_matrix_format",
     "cgx_solve", "cgx_solve_begin", "cgx_solve_steps", "cgx_solve_end", "cgx_get_gemv_samples",
     "cgx_probe_gemv", "cgx_probe_time_gemv", "cgx_probe_vector_ops", "cgx_probe_get_matrix_rows",
+    "cgx_probe_get_source_term", "cgx_probe_set_fault_after",
 ]
 
 
@@ -114,6 +115,8 @@ def lib():
         L.cgx_probe_time_gemv.argtypes = [vp, C.c_int, dp]
         L.cgx_probe_vector_ops.argtypes = [vp, C.c_int, C.c_double, C.c_double, dp, dp, dp, dp, dp]
         L.cgx_probe_get_matrix_rows.argtypes = [vp, C.c_int, dp, ip, ip]
+        L.cgx_probe_get_source_term.argtypes = [vp, C.c_int, dp]
+        L.cgx_probe_set_fault_after.argtypes = [vp, C.c_int]
         for name in EXPORTS:
             fn = getattr(L, name)
             if fn.restype is C.c_int and name not in ("cgx_config_init",):
@@ -327,6 +330,16 @@ class CGSolver:
         self._check(lib().cgx_probe_vector_ops(self._h, x.size, alpha, beta, _dp(x), _dp(r), _dp(p), _dp(Ap),
                                                C.byref(rr)))
         return x, r, p, rr.value
+
+    def _set_fault_after(self, calls):
+        """Error-path tests: the HIP call after `calls` more of this context fails (-1 = off)."""
+        lib().cgx_probe_set_fault_after(self._h, int(calls))
+
+    def probe_source_term(self, local_shard=0):
+        """The device copy of b (n doubles) of a local shard."""
+        b = np.zeros(self.n(), dtype=np.float64)
+        self._check(lib().cgx_probe_get_source_term(self._h, int(local_shard), _dp(b)))
+        return b
 
     def probe_matrix_rows(self, local_shard=0):
         row0 = C.c_int()

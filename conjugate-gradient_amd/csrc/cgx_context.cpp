@@ -365,6 +365,7 @@ cgx_status cgx_create(cgx_ctx **out, const cgx_config *cfg_in)
         ctx->mv.base[cfg.rank] = ctx->mailbox;
         if (cfg.nranks == 1) ctx->p2p_ready = true;
     }
+    if (const char *fa = getenv("CGX_FAULT_AFTER")) ctx->fault_after = atoi(fa);   // error-path tests only (cgx_internal.h)
     *out = ctx;
     return CGX_OK;
 }
@@ -437,25 +438,27 @@ cgx_status cgx_p2p_selftest(cgx_ctx *ctx, int rounds, int *ok)
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int P = ctx->nranks, me = ctx->cfg.rank;
     const int count = 1024;   // doubles per rank: 8 KiB, the size class of the real exchanges
-    cgx::MailboxView saved = ctx->mv;
+    // the mailbox is re-laid-out for the test and put back on EVERY return path; so are the two device buffers
+    struct RestoreView {
+        cgx_ctx *c;
+        cgx::MailboxView saved;
+        ~RestoreView() { c->mv = saved; }
+    } restore{ctx, ctx->mv};
     ctx->mv.data_off[1] = p2p_fixed_prefix(P);
     ctx->mv.slot_bytes[1] = (long)count * 8;
-    if ((size_t)(ctx->mv.data_off[1] + 2L * P * count * 8) > ctx->mailbox_bytes) {
-        ctx->mv = saved;
+    if ((size_t)(ctx->mv.data_off[1] + 2L * P * count * 8) > ctx->mailbox_bytes)
         return fail(ctx, CGX_ERR_P2P, "mailbox too small for the self-test");
-    }
+    DeviceScratch scratch;
     double *dsrc = nullptr, *ddst = nullptr;
-    HIP_TRY(ctx, hipMalloc(&dsrc, (size_t)count * sizeof(double)));
-    HIP_TRY(ctx, hipMalloc(&ddst, (size_t)P * count * sizeof(double)));
+    HIP_TRY(ctx, scratch.alloc(&dsrc, (size_t)count * sizeof(double)));
+    HIP_TRY(ctx, scratch.alloc(&ddst, (size_t)P * count * sizeof(double)));
     std::vector<double> hsrc(count), hdst((size_t)P * count);
     bool good = true;
-    cgx_status st = CGX_OK;
     for (int r = 0; r < rounds && good; ++r) {
         for (int i = 0; i < count; ++i) hsrc[i] = 1e6 * (me + 1) + 1e3 * r + i + 0.25;
         HIP_TRY(ctx, hipMemcpyAsync(dsrc, hsrc.data(), count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ddst, 0, (size_t)P * count * sizeof(double), ctx->stream));
-        st = p2p_allgather(ctx, 1, dsrc, count, ddst, count, 1);
-        if (st != CGX_OK) break;
+        CGX_TRY(p2p_allgather(ctx, 1, dsrc, count, ddst, count, 1));
         HIP_TRY(ctx, hipMemcpyAsync(hdst.data(), ddst, (size_t)P * count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (check_p2p_error(ctx) != CGX_OK) { good = false; break; }
@@ -463,10 +466,6 @@ cgx_status cgx_p2p_selftest(cgx_ctx *ctx, int rounds, int *ok)
             for (int i = 0; i < count; ++i)
                 if (hdst[(size_t)q * count + i] != 1e6 * (q + 1) + 1e3 * r + i + 0.25) { good = false; break; }
     }
-    (void)hipFree(dsrc);
-    (void)hipFree(ddst);
-    ctx->mv = saved;
-    if (st != CGX_OK) return st;
     *ok = good ? 1 : 0;
     return CGX_OK;
 }

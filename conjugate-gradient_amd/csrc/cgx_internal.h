@@ -95,6 +95,8 @@ struct cgx_ctx {
     long long gemv_seq = 0;              // K1 launches of the current cgx_solve_steps call
     std::vector<float> gemv_samples;     // their durations (ms), most recent steps call
 
+    int fault_after = -1;     // >= 0: HIP_TRY calls left until one is made to fail (CGX_FAULT_AFTER, error-path tests only)
+
     std::string err;
 };
 
@@ -106,9 +108,19 @@ extern thread_local std::string g_create_error;   // error of the last failed cg
 double wall_now();
 cgx_status fail(cgx_ctx *ctx, cgx_status st, const std::string &msg);
 
+// Fault injection for the error-path tests (tools/leak_check.py, tests): with CGX_FAULT_AFTER=N in the environment of
+// cgx_create, the (N+1)-th HIP call of the context made through HIP_TRY is not made and reports hipErrorUnknown instead.
+inline bool fault_due(cgx_ctx *ctx)
+{
+    if (!ctx || ctx->fault_after < 0) return false;
+    if (ctx->fault_after == 0) { ctx->fault_after = -1; return true; }
+    --ctx->fault_after;
+    return false;
+}
+
 #define HIP_TRY(ctx, call)                                                                              \
     do {                                                                                                \
-        hipError_t e_ = (call);                                                                         \
+        hipError_t e_ = cgxi::fault_due(ctx) ? hipErrorUnknown : (call);                                \
         if (e_ != hipSuccess) {                                                                         \
             cgx_status st_ = (e_ == hipErrorOutOfMemory) ? CGX_ERR_OOM                                  \
                              : (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? CGX_ERR_NO_DEVICE \
@@ -130,6 +142,36 @@ cgx_status fail(cgx_ctx *ctx, cgx_status st, const std::string &msg);
         if (s_ != CGX_OK) return s_;       \
     } while (0)
 
+
+// Device allocations and events of ONE function: released on every return path (hipFree waits for the device, so work
+// still queued on a buffer when an error return unwinds is finished first).
+struct DeviceScratch {
+    std::vector<void *> ptrs;
+    std::vector<hipEvent_t> events;
+    DeviceScratch() = default;
+    DeviceScratch(const DeviceScratch &) = delete;
+    DeviceScratch &operator=(const DeviceScratch &) = delete;
+    ~DeviceScratch()
+    {
+        for (void *p : ptrs) (void)hipFree(p);
+        for (hipEvent_t e : events) (void)hipEventDestroy(e);
+    }
+    template <class T>
+    hipError_t alloc(T **out, size_t bytes)
+    {
+        void *p = nullptr;
+        const hipError_t e = hipMalloc(&p, bytes);
+        if (e == hipSuccess) ptrs.push_back(p);
+        *out = static_cast<T *>(p);
+        return e;
+    }
+    hipError_t event(hipEvent_t *out)
+    {
+        const hipError_t e = hipEventCreate(out);
+        if (e == hipSuccess) events.push_back(*out);
+        return e;
+    }
+};
 
 // cgx_context.cpp
 void partition_rows(int N, int psize, int *start_rows, int *num_rows);

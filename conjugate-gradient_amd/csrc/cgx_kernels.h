@@ -52,6 +52,7 @@ struct GemvPlan {
     int nt;          // non-temporal loads of A
     int grid;        // workgroups
     int rows_per_wg;
+    int light;       // variant 1: the one-round form (grid <= 512 workgroups, at most two per CU; see k_gemv_colsplit)
 };
 
 // Choose the K1 shape for a shard of `rows` x `ncols` (variant 0 = default).

@@ -37,6 +37,14 @@ typedef double d2 __attribute__((ext_vector_type(2)));
 
 static constexpr double kNearZero = 1.0e-14;   // NEARZERO, code/MPI/cg.cc:8
 
+// alpha = rsold / std::max(conj, rsold * NEARZERO), cg.cc:107.  std::max(a, b) is (a < b) ? b : a: a NaN p.Ap stays a
+// NaN (the comparison is false), a NaN bound is ignored.  fmax would return the other operand in both cases.
+__device__ __forceinline__ double safeguarded_alpha(double rsold, double conj)
+{
+    const double bound = rsold * kNearZero;
+    return rsold / ((conj < bound) ? bound : conj);
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // reductions: fixed order => bitwise reproducible for a given launch shape
@@ -120,6 +128,9 @@ __device__ __forceinline__ IterHead iteration_head(Scalars *sc, const SegView &s
     IterHead h{0.0, false};
     double v = 0.0;
     const int nparts = sv.S - sv.Sr;
+    // rsold was stored by the previous K1: its load does not depend on the fold, so it goes out with the partials
+    // (one memory round trip for the whole head instead of two)
+    const double rsold = sc->rs[(k > 0 ? k - 1 : 0) & 1];
     for (int t = threadIdx.x; t < nparts; t += WAVES * 64) v += sv.base[sv.Sr + t];
     const double rsnew = block_sum<WAVES>(v, lds);                   // r.r over all rows, cg.cc:116-117 (k==0: cg.cc:91-92)
     const bool first = (blockIdx.x == 0 && threadIdx.x == 0) && !sc->done;   // nothing is written once converged
@@ -127,7 +138,6 @@ __device__ __forceinline__ IterHead iteration_head(Scalars *sc, const SegView &s
         if (first) { sc->rs[0] = rsnew; sc->rs[1] = rsnew; }
         return h;
     }
-    const double rsold = sc->rs[(k - 1) & 1];
     if (first) sc->rs[k & 1] = rsnew;                                // rsold = rsnew, cg.cc:132
     if (sqrt(rsnew) < tol) {                                         // cg.cc:120-121: break before the p update
         if (first) { sc->k_final = k - 1; sc->done = 1; }
@@ -169,8 +179,12 @@ __device__ __forceinline__ d2 make_p(const SegView &sv, double beta, d2 p_old, i
 // ------------------------------------------------------------------------------------------------
 // The default shape (8,2) is held to 128 VGPRs = 4 workgroups per CU (the 4096-workgroup grid of N=32768 then runs in
 // exactly 4 rounds; at 3 per CU it needs 5.33 and loses ~1.2 %, measured).
-template <int R, int U, int WAVES, int MODE>
-__global__ __launch_bounds__(WAVES * 64, ((R == 8 && U == 2) ? 4 : 1)) void k_gemv_colsplit(const double *__restrict__ A, long lda, int rows,
+// LIGHT: for grids that are resident all at once at no more than two workgroups per CU (the shard of an 8-GPU run:
+// 4096 rows = 512 workgroups).  Such a launch has one round, so whatever a workgroup does before its first load and
+// after its last one is paid in full by the whole launch.  With 256 registers to spend, the first trip's loads go out
+// before the iteration head and the epilogue's two vector operands are fetched before the sweep.
+template <int R, int U, int WAVES, int MODE, bool LIGHT = false>
+__global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 1))) void k_gemv_colsplit(const double *__restrict__ A, long lda, int rows,
                                                                int row0_global, const double *__restrict__ v,
                                                                double *__restrict__ p_new, SegView sv,
                                                                double *__restrict__ Ap, double *partials,
@@ -246,9 +260,18 @@ __global__ __launch_bounds__(WAVES * 64, ((R == 8 && U == 2) ? 4 : 1)) void k_ge
     // head's dependent loads and its block reduction overlap the first HBM round trip instead of preceding it.
     // Only for the light shapes: with R*U = 16 the 80 extra live registers push the kernel past 128 VGPRs
     // (3 workgroups per CU: the 4096-workgroup grid of N=32768 then runs 5.33 rounds instead of 4, -1.2 %).
-    constexpr bool HOIST = R * U <= 8;
+    constexpr bool HOIST = LIGHT || R * U <= 8;
     const bool first = HOIST && c + (U - 1) * kStep < ncols;
     if (first) load_trip(c);
+    // LIGHT: the epilogue's operands (p_old and r of the workgroup's own rows) are fetched now instead of behind the sweep
+    double ep_v = 0.0, ep_r = 0.0;
+    if constexpr (LIGHT) {
+        if (w == 0 && lane < R && row0 + lane < rows) {
+            const int j = row0_global + (int)(row0 + lane);
+            ep_v = v[j];
+            if constexpr (FUSED) ep_r = seg_load(sv, j);
+        }
+    }
     if constexpr (FUSED) {
         __shared__ double head_lds[WAVES];
         const int done = sc->done;       // converged earlier: the whole grid drains immediately
@@ -304,8 +327,8 @@ __global__ __launch_bounds__(WAVES * 64, ((R == 8 && U == 2) ? 4 : 1)) void k_ge
             if (row < rows) {
                 Ap[row] = s;
                 const int j = row0_global + (int)row;
-                double pl = v[j];
-                if constexpr (FUSED) pl = fma(beta, pl, seg_load(sv, j));   // same bits as the stored p_new[j]
+                double pl = LIGHT ? ep_v : v[j];
+                if constexpr (FUSED) pl = fma(beta, pl, LIGHT ? ep_r : seg_load(sv, j));   // same bits as the stored p_new[j]
                 d = pl * s;                                                 // cg.cc:105
             }
         }
@@ -496,7 +519,7 @@ __global__ __launch_bounds__(256) void k_update_xr(int n, int rows, int row0, co
     }
     if (done) return;   // converged earlier (uniform over the grid): nothing is written
     const double conj = block_sum<4>(cs, lds);
-    const double alpha = rsold / fmax(conj, rsold * kNearZero);      // cg.cc:107
+    const double alpha = safeguarded_alpha(rsold, conj);             // cg.cc:107
     double rr = 0.0;
     if (in) {
         const double rn = fma(-alpha, ap_i, r_i);                     // cg.cc:113, for every row (r is replicated)
@@ -645,7 +668,7 @@ __global__ __launch_bounds__(256) void k_update_xr_strided(int n, int rows, int 
     }
     if (done) return;
     const double conj = block_sum<4>(cs, lds);
-    const double alpha = rsold / fmax(conj, rsold * kNearZero);      // cg.cc:107
+    const double alpha = safeguarded_alpha(rsold, conj);             // cg.cc:107
     double rr = 0.0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const double rn = fma(-alpha, seg_load(apv, (int)i), r[i]);   // cg.cc:113
@@ -1028,7 +1051,7 @@ __global__ __launch_bounds__(256) void k_update_xr_p2p(int n, int rows, int row0
     __syncthreads();
     double conj = s_sums[0];
     for (int q = 1; q < P; ++q) conj += s_sums[q];                   // rank order: bit-identical on every rank (cg.cc:106)
-    const double alpha = rsold / fmax(conj, rsold * kNearZero);      // cg.cc:107
+    const double alpha = safeguarded_alpha(rsold, conj);             // cg.cc:107
     double rr = 0.0;
     if (in) {
         const double rn = fma(-alpha, ap_i, r_i);                     // cg.cc:113
@@ -1078,15 +1101,24 @@ GemvPlan plan_gemv(int variant, int rows, int ncols)
         pl.variant = 1;
         pl.nt = 1;
         const double block_bytes = 8.0 * (double)rows * (double)ncols;
-        if (rows >= 2048 && block_bytes > 256.0 * 1024 * 1024) { pl.R = 8; pl.U = 2; }
+        //  - row blocks of 8192 rows or fewer that still stream from HBM (the shards of a 4- and 8-GPU run of N = 32768):
+        //    the one-round form with 4 rows x 4 steps, 155.5 us against 157.8 on 4096 x 32768 and 306.7 against 309.2
+        //    on 8192 x 32768 (profiles/r02_k1_shards/); up to 16384 rows the one-round form of (8,2): 605.2 against 608.5.
+        if (rows >= 2048 && block_bytes > 256.0 * 1024 * 1024) {
+            if (rows <= 8192) { pl.R = 4; pl.U = 4; pl.light = 1; }
+            else if (rows <= 16384) { pl.R = 8; pl.U = 2; pl.light = 1; }
+            else { pl.R = 8; pl.U = 2; }
+        }
         else if (rows >= 512) { pl.R = 4; pl.U = 2; }
         else { pl.R = 2; pl.U = 4; }
     } else {
-        // explicit shape: variant*10000 + R*100 + U*10 + 1   (e.g. 10821, 20441, 11611); the last digit is ignored
+        // explicit shape: variant*10000 + R*100 + U*10 + d   (e.g. 10821, 20441, 11611); d = 2 selects the one-round
+        // form of the column-split kernel (10822, 10842, 10442, 10482), any other digit the ordinary one
         pl.variant = variant / 10000;
         pl.R = (variant / 100) % 100;
         pl.U = (variant / 10) % 10;
-        pl.nt = variant % 10;
+        pl.nt = 1;
+        pl.light = (variant % 10) == 2;   // last digit 2: the one-round form (two workgroups per CU at most)
     }
     if (pl.variant == 2) {
         pl.rows_per_wg = pl.R * pl.waves;
@@ -1096,6 +1128,7 @@ GemvPlan plan_gemv(int variant, int rows, int ncols)
     }
     pl.grid = ceil_div(rows, pl.rows_per_wg);
     if (pl.grid < 1) pl.grid = 1;   // a shard without rows still runs the iteration head and stores p
+    if (pl.variant != 1) pl.light = 0;   // (an explicit one-round shape is honoured at any grid: it is correct, just not one round)
     return pl;
 }
 
@@ -1127,9 +1160,24 @@ hipError_t launch_shape(const GemvPlan &pl, const GemvArgs &g, hipStream_t s)
     return hipGetLastError();
 }
 
+template <int R, int U, int MODE>
+hipError_t launch_light(const GemvPlan &pl, const GemvArgs &g, hipStream_t s)
+{
+    hipExtLaunchKernelGGL((k_gemv_colsplit<R, U, 4, MODE, true>), dim3(pl.grid), dim3(256), 0, s, g.e0, g.e1, 0, g.A, g.lda,
+                          g.rows, g.row0, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol);
+    return hipGetLastError();
+}
+
 template <int MODE>
 hipError_t dispatch_gemv(const GemvPlan &pl, const GemvArgs &g, hipStream_t s)
 {
+    if (pl.light && pl.variant == 1) {
+        if (pl.R == 8 && pl.U == 2) return launch_light<8, 2, MODE>(pl, g, s);
+        if (pl.R == 8 && pl.U == 4) return launch_light<8, 4, MODE>(pl, g, s);
+        if (pl.R == 4 && pl.U == 4) return launch_light<4, 4, MODE>(pl, g, s);
+        if (pl.R == 4 && pl.U == 8) return launch_light<4, 8, MODE>(pl, g, s);
+        return hipErrorInvalidValue;
+    }
 #define CGX_SHAPE(r, u) \
     if (pl.R == r && pl.U == u) return launch_shape<r, u, MODE>(pl, g, s);
     CGX_SHAPE(8, 2)

@@ -45,9 +45,10 @@ cgx_status cgx_probe_time_gemv(cgx_ctx *ctx, int reps, double *ms_per_launch)
     if (!ctx->have_matrix) return fail(ctx, CGX_ERR_BAD_ARG, "no matrix");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    hipEvent_t e0, e1;
-    HIP_TRY(ctx, hipEventCreate(&e0));
-    HIP_TRY(ctx, hipEventCreate(&e1));
+    DeviceScratch scratch;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIP_TRY(ctx, scratch.event(&e0));
+    HIP_TRY(ctx, scratch.event(&e1));
     for (auto &s : ctx->shards) HIP_TRY(ctx, hipMemsetAsync(s.sc, 0, sizeof(Scalars), st));
     for (auto &s : ctx->shards) CGX_TRY(run_gemv_plain(ctx, s, s.p[0]));   // warm
     HIP_TRY(ctx, hipEventRecord(e0, st));
@@ -57,8 +58,6 @@ cgx_status cgx_probe_time_gemv(cgx_ctx *ctx, int reps, double *ms_per_launch)
     HIP_TRY(ctx, hipEventSynchronize(e1));
     float ms = 0.f;
     HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     *ms_per_launch = (double)ms / reps / (double)ctx->shards.size();
     return CGX_OK;
 }
@@ -78,15 +77,16 @@ cgx_status cgx_probe_vector_ops(cgx_ctx *ctx, int n, double alpha, double beta, 
     double *dx = nullptr, *dp0 = nullptr, *dp1 = nullptr, *dap = nullptr, *drb = nullptr, *dpart = nullptr, *dA = nullptr,
            *dAp1 = nullptr;
     Scalars *dsc = nullptr;
-    HIP_TRY(ctx, hipMalloc(&dx, bytes));
-    HIP_TRY(ctx, hipMalloc(&dp0, vbytes));
-    HIP_TRY(ctx, hipMalloc(&dp1, vbytes));
-    HIP_TRY(ctx, hipMalloc(&dap, (size_t)S * sizeof(double)));
-    HIP_TRY(ctx, hipMalloc(&drb, (size_t)(lda + grid) * sizeof(double)));
-    HIP_TRY(ctx, hipMalloc(&dpart, (size_t)(grid + 8) * sizeof(double)));
-    HIP_TRY(ctx, hipMalloc(&dA, vbytes));
-    HIP_TRY(ctx, hipMalloc(&dAp1, 64 * sizeof(double)));
-    HIP_TRY(ctx, hipMalloc(&dsc, sizeof(Scalars)));
+    DeviceScratch scratch;   // nine buffers: freed on every return path below
+    HIP_TRY(ctx, scratch.alloc(&dx, bytes));
+    HIP_TRY(ctx, scratch.alloc(&dp0, vbytes));
+    HIP_TRY(ctx, scratch.alloc(&dp1, vbytes));
+    HIP_TRY(ctx, scratch.alloc(&dap, (size_t)S * sizeof(double)));
+    HIP_TRY(ctx, scratch.alloc(&drb, (size_t)(lda + grid) * sizeof(double)));
+    HIP_TRY(ctx, scratch.alloc(&dpart, (size_t)(grid + 8) * sizeof(double)));
+    HIP_TRY(ctx, scratch.alloc(&dA, vbytes));
+    HIP_TRY(ctx, scratch.alloc(&dAp1, 64 * sizeof(double)));
+    HIP_TRY(ctx, scratch.alloc(&dsc, sizeof(Scalars)));
     cgx::SegView apv{dap, S, Sr, n, 1, n, 0, 0, 0, 0};
     cgx::seg_finalize(&apv);
     cgx::SegView rv{drb, (int)lda + grid, (int)lda, n, 1, n, 0, 0, 0, 0};
@@ -123,8 +123,24 @@ cgx_status cgx_probe_vector_ops(cgx_ctx *ctx, int n, double alpha, double beta, 
     HIP_TRY(ctx, hipMemcpyAsync(p, dp1, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
     if (rr) *rr = rr_host;
-    (void)hipFree(dx); (void)hipFree(dp0); (void)hipFree(dp1); (void)hipFree(dap); (void)hipFree(drb);
-    (void)hipFree(dpart); (void)hipFree(dA); (void)hipFree(dAp1); (void)hipFree(dsc);
+    return CGX_OK;
+}
+
+cgx_status cgx_probe_set_fault_after(cgx_ctx *ctx, int calls)
+{
+    if (!ctx) return CGX_ERR_BAD_ARG;
+    ctx->fault_after = calls;
+    return CGX_OK;
+}
+
+// The DEVICE copy of b on local shard `local_shard` (n doubles): what init_source_term (cg.cc:218-234) left in HBM.
+cgx_status cgx_probe_get_source_term(cgx_ctx *ctx, int local_shard, double *b_out)
+{
+    if (!ctx || !b_out || local_shard < 0 || local_shard >= (int)ctx->shards.size())
+        return fail(ctx, CGX_ERR_BAD_ARG, "cgx_probe_get_source_term: bad argument");
+    if (!ctx->have_b) return fail(ctx, CGX_ERR_BAD_ARG, "no source term");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpy(b_out, ctx->shards[local_shard].b_full, (size_t)ctx->n * sizeof(double), hipMemcpyDeviceToHost));
     return CGX_OK;
 }
 

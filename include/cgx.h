@@ -183,7 +183,7 @@ cgx_status  cgx_solve_steps(cgx_ctx *ctx, int nsteps, int *done_out);
 cgx_status  cgx_solve_end(cgx_ctx *ctx, double *x, cgx_result *res);
 /* The individual K1 durations (ms, HIP events on the library's stream) of the most recent cgx_solve_steps call, in
  * launch order: at most `cap` are written, *count receives how many exist.  bench.py reports their median. */
-cgx_status  cgx_get_gemv_samples(const cgx_ctx *ctx, double *ms_out, int cap, int *count);
+cgx_status  cgx_get_gemv_samples(cgx_ctx *ctx, double *ms_out, int cap, int *count);
 
 /* ---- kernel probes (parity tests of the individual hot ops through the C ABI) ------------- */
 /* Ap = A_shard * p  (K1; cblas_dgemv at cg.cc:101-102) for every local shard; y receives the n
@@ -196,6 +196,13 @@ cgx_status  cgx_probe_time_gemv(cgx_ctx *ctx, int reps, double *ms_per_launch);
  * data of length n, single shard: x += alpha p; r -= alpha Ap; *rr = r.r; p = r + beta p. */
 cgx_status  cgx_probe_vector_ops(cgx_ctx *ctx, int n, double alpha, double beta, double *x, double *r,
                                  double *p, const double *Ap, double *rr);
+/* Error-path testing: after `calls` further HIP runtime calls of this context the next one is not made and reports a
+ * failure instead (-1 = off; the same as CGX_FAULT_AFTER in the environment of cgx_create).  tools/leak_check.py and
+ * tests/ use it to walk every early return of a probe, the self-test and the solve. */
+cgx_status  cgx_probe_set_fault_after(cgx_ctx *ctx, int calls);
+/* Copy the device-resident source term of local shard `local_shard` (n doubles, what cgx_init_source_term /
+ * cgx_set_source_term left in HBM) back to the host: the bit-exact check of cg.cc:230-231. */
+cgx_status  cgx_probe_get_source_term(cgx_ctx *ctx, int local_shard, double *b_out);
 /* Copy this shard's device row block (rows x n, dense, row-major) back to the host (banded storage is expanded). */
 cgx_status  cgx_probe_get_matrix_rows(cgx_ctx *ctx, int local_shard, double *A_out, int *row0, int *rows);
 

@@ -205,7 +205,7 @@ static int solve_blocks(rank_state *rk, int psize, const double *b, double *x, i
         }
         for (int q = 0; q < psize; ++q) conj += rk[q].part;              /* MPI_Allreduce, cg.cc:106 */
         double safe = rsold * NEARZERO;
-        double alpha = rsold / (conj > safe ? conj : safe);               /* cg.cc:107 */
+        double alpha = rsold / ((conj < safe) ? safe : conj);             /* cg.cc:107: std::max(a, b) is (a < b) ? b : a, so a NaN conj stays NaN */
         rsnew = 0.0;
         for (int q = 0; q < psize; ++q) {
             rank_state *s = &rk[q];

@@ -72,7 +72,8 @@ def main():
         Ap = O.gemv(A, p) if rows else np.zeros(0)
         pl = p[r0:r0 + rows]
         Ap_full, conj = exchange(Ap, O.dot(pl, Ap) if rows else 0.0)
-        alpha = rsold / max(conj, rsold * NEARZERO)
+        safe = rsold * NEARZERO
+        alpha = rsold / (safe if conj < safe else conj)  # std::max(conj, safe), cg.cc:107
         x = x + alpha * pl
         r = r - alpha * Ap_full                         # every rank updates ALL of r ...
         rsnew = O.dot(r, r)                             # ... and reduces it identically: no second all-reduce

@@ -53,7 +53,8 @@ def test_generator_bit_exact(gpu_pkg, oracle, n, mode, p):
 
 
 # ---- K1 ------------------------------------------------------------------------------------------------
-VARIANTS = [0, 10821, 10820, 10811, 10441, 10421, 10241, 10281, 10181, 11611, 20821, 20811, 20441, 20421, 20241, 20281, 20181]
+VARIANTS = [0, 10821, 10820, 10811, 10441, 10421, 10241, 10281, 10181, 11611, 20821, 20811, 20441, 20421, 20241, 20281, 20181,
+            10822, 10842, 10442, 10482]   # last digit 2: the one-round form of the column-split kernel (shards of an 8-GPU run)
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -69,7 +70,7 @@ def test_gemv_generated(gpu_pkg, oracle, n, variant):
     assert abs(pap - oracle.dot(p, yo)) <= 1e-12 * np.sum(np.abs(p * yo))
 
 
-@pytest.mark.parametrize("variant", [0, 10821, 10441, 20821, 20441])
+@pytest.mark.parametrize("variant", [0, 10821, 10441, 20821, 20441, 10822, 10842])
 @pytest.mark.parametrize("n", [5, 300, 1000, 2047])
 def test_gemv_dense_random(gpu_pkg, oracle, n, variant):
     """Fully dense random A (every element matters, unlike the 5-band generator) incl. odd n."""
@@ -143,11 +144,64 @@ def test_vector_ops(gpu_pkg, oracle, n):
     assert rel(rr, oracle.dot(re_, re_)) < 1e-13
 
 
+# ---- init_source_term, the safeguard of alpha -----------------------------------------------------------------------
+@pytest.mark.parametrize("n,mode,p", [(1, None, 1), (1000, None, 1), (4096, None, 1), (10000, 1, 3), (32768, None, 1)])
+def test_source_term_is_bit_exact(gpu_pkg, oracle, n, mode, p):
+    """b[i] = -2.*i*M_PI*M_PI*sin(10.*M_PI*i*h)*sin(10.*M_PI*i*h) (cg.cc:230-231), read back from the device copy of
+    every shard: identical bits to the oracle's evaluation with the same libm (h = 1/n as cg_main.cc:45-46, and another h)."""
+    for h in (1.0 / n, 0.37 / n):
+        with make(gpu_pkg, n, mode, p) as s:
+            s.init_source_term(h)
+            for shard in range(p):
+                assert np.array_equal(s.probe_source_term(shard), oracle.init_source_term(n, h))
+
+
+@pytest.mark.parametrize("mode,p", [(None, 1), (1, 2), (1, 5)])
+def test_alpha_safeguard_branch(gpu_pkg, oracle, mode, p):
+    """A = -I makes p.Ap = -rsold < rsold*NEARZERO in every iteration, so alpha = rsold / (rsold*1e-14) (cg.cc:107, the
+    second operand of std::max): the branch no SPD input reaches.  Values grow by ~1e28 per iteration."""
+    n = 96
+    rng = np.random.default_rng(5)
+    b = rng.standard_normal(n)
+    A = -np.eye(n)
+    with gpu_pkg.CGSolver(comm_mode=gpu_pkg.COMM_SELF if mode is None else mode, nranks=p) as s:
+        s.set_matrix_dense(A)
+        s.set_source_term(b)
+        s.set_max_iter(3)
+        x = np.zeros(n)
+        r = s.solve(x)
+    xo, ro = oracle.solve(A, b, None, 3, 1e-10, p)
+    assert r["iterations"] == ro["iterations"] == 3
+    x1 = 1e14 * b                                        # first step by hand: alpha = rsold / (rsold * 1e-14)
+    assert np.all(np.isfinite(x)) and np.linalg.norm(x) > 1e40 and np.linalg.norm(x1) > 1e14
+    assert np.linalg.norm(x - xo) <= 1e-12 * np.linalg.norm(xo)
+    assert rel(r["residual_prev"], ro["residual_prev"]) < 1e-12
+
+
+def test_alpha_safeguard_keeps_a_nan_like_std_max(gpu_pkg, oracle):
+    """std::max(conj, rsold*NEARZERO) (cg.cc:107) returns conj when conj is NaN: alpha and then all of x become NaN.
+    fmax would have returned the bound and hidden it.  A has one NaN entry; b is finite."""
+    n = 64
+    A = np.eye(n)
+    A[0, 0] = np.nan
+    b = np.ones(n)
+    for mode, p in ((None, 1), (1, 2)):
+        with gpu_pkg.CGSolver(comm_mode=gpu_pkg.COMM_SELF if mode is None else mode, nranks=p) as s:
+            s.set_matrix_dense(A)
+            s.set_source_term(b)
+            s.set_max_iter(1)
+            x = np.zeros(n)
+            s.solve(x)
+        xo, _ = oracle.solve(A, b, None, 1, 1e-10, p)
+        assert np.all(np.isnan(xo)) and np.all(np.isnan(x))
+
+
 # ---- whole solve vs oracle -----------------------------------------------------------------------------------
 @pytest.mark.parametrize("n,max_iter,mode,p,variant", [
     (64, 10, None, 1, 0), (1000, 100, None, 1, 0), (1024, 100, None, 1, 20441), (2048, 200, None, 1, 0),
     (2048, 200, 1, 2, 0), (2048, 200, 1, 4, 0), (2048, 200, 1, 8, 10821), (1000, 150, 1, 3, 0), (1000, 150, 1, 7, 20441),
     (4096, 50, None, 1, 0), (4096, 200, 1, 8, 0),
+    (2048, 200, 1, 8, 10822), (1000, 150, 1, 3, 10842), (4096, 50, None, 1, 10822), (1024, 100, None, 1, 10482),
 ])
 def test_fixed_iteration_solve_matches_oracle(gpu_pkg, oracle, n, max_iter, mode, p, variant):
     with make(gpu_pkg, n, mode, p, variant, max_iter) as s:
@@ -433,6 +487,20 @@ def test_mtx_solve_matches_reference_golden(gpu_pkg, mtx_path, reference_probe):
         assert rel(x[int(i)], v) < 1e-10, i
 
 
+def test_mtx_solve_matches_the_oracle_run_to_convergence(gpu_pkg, mtx_path, oracle_large):
+    """The same input against the committed oracle run to convergence (tests/golden/oracle_large.json, 20 sampled
+    entries of x at full precision): both stop below 1e-10 at their own k, the solutions agree far below the 1e-10 bar."""
+    row = oracle_large["mtx"][0]
+    with make(gpu_pkg, mtx=mtx_path) as s:
+        x = np.zeros(10000)
+        r = s.solve(x)
+    assert r["converged"] and abs(r["iterations"] - row["k"]) <= 0.15 * row["k"]
+    assert rel(r["x_norm"], row["x_norm"]) < 1e-12 and r["rel_residual"] <= 1e-11
+    assert len(row["x_samples"]) >= 16
+    for i, v in row["x_samples"].items():
+        assert rel(x[int(i)], v) < 1e-11, i
+
+
 # ---- BASELINE.json sizes against the reference's own outputs -----------------------------------------------------
 def _check_against_reference(x, r, row):
     assert r["iterations"] == row["k"]
@@ -453,7 +521,8 @@ def test_config2_n10000_converges_like_reference(gpu_pkg, reference_probe):
     assert rel(r["x_norm"], row["x_norm"]) < 1e-6 and r["rel_residual"] <= 3e-11
 
 
-@pytest.mark.parametrize("mode,p,variant", [(None, 1, 0), (1, 2, 0), (1, 4, 0), (1, 8, 0), (None, 1, 20441), (1, 8, 20241)])
+@pytest.mark.parametrize("mode,p,variant", [(None, 1, 0), (1, 2, 0), (1, 4, 0), (1, 8, 0), (None, 1, 20441), (1, 8, 20241),
+                                            (1, 8, 10822), (1, 8, 10842)])
 def test_config3_n32768_500_iterations(gpu_pkg, reference_probe, mode, p, variant):
     """The roofline point and (as 2/4/8 logical row blocks on one GPU) the strong-scaling partitions, with the default
     K1 and with the LDS-staged variant."""
@@ -472,6 +541,16 @@ def test_config5_weak_scaling_sizes(gpu_pkg, reference_probe, n, p):
     row = [q for q in reference_probe["generated_large"] if q["n"] == n][0]
     with make(gpu_pkg, n, gpu_pkg.COMM_LOOPBACK if p > 1 else None, p, max_iter=200) as s:
         x = np.zeros(n)
+        r = s.solve(x)
+    _check_against_reference(x, r, row)
+
+
+def test_config5_weak_scaling_n32768_p4(gpu_pkg, oracle_large):
+    """The fourth point of the weak-scaling series, (N=32768, P=4, 200 iterations), which the reference probe did not
+    capture: against the oracle's committed row (25 sampled entries of x), same bars as the reference rows."""
+    row = [q for q in oracle_large["cases"] if q["n"] == 32768 and q["max_iter"] == 200 and q["psize"] == 4][0]
+    with make(gpu_pkg, 32768, gpu_pkg.COMM_LOOPBACK, 4, max_iter=200) as s:
+        x = np.zeros(32768)
         r = s.solve(x)
     _check_against_reference(x, r, row)
 
@@ -528,3 +607,38 @@ def test_cgsolver_cli_both_forms(gpu_pkg, mtx_path, tmp_path):
     assert r.returncode == 0, r.stderr
     assert r.stdout.startswith("\t[STEP 100] residual = ")
     assert out3.read_text().strip().startswith("10000,2,")
+
+
+# ---- error paths -------------------------------------------------------------------------------------------------------
+def test_error_paths_release_device_memory(gpu_pkg):
+    """Every HIP call of cgx_probe_vector_ops and of cgx_p2p_selftest is made to fail in turn (cgx_probe_set_fault_after):
+    the call reports CGX_ERR_HIP, the device's free memory is back where it was, and the context still works."""
+    import torch
+
+    def free_mb():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0] / 2**20
+
+    rng = np.random.default_rng(3)
+    v = [rng.standard_normal(200000) for _ in range(4)]
+    with gpu_pkg.CGSolver(comm_mode=gpu_pkg.COMM_P2P, nranks=1) as s:
+        s.generate_lap2d_matrix(512)
+        good = s.probe_vector_ops(0.5, 0.25, *v)
+        assert s.p2p_selftest(2)
+        base, failures = free_mb(), 0
+        for act in (lambda: s.probe_vector_ops(0.5, 0.25, *v), lambda: s.p2p_selftest(2)):
+            for k in range(120):
+                s._set_fault_after(k)
+                try:
+                    act()
+                    s._set_fault_after(-1)
+                    break                                    # k is past the last HIP call of the action
+                except gpu_pkg.CgxError as e:
+                    assert e.status == 3
+                    failures += 1
+                s._set_fault_after(-1)
+                assert abs(free_mb() - base) < 4, k         # 4 x 1.6 MB vectors + scratch would show
+        assert failures >= 20
+        again = s.probe_vector_ops(0.5, 0.25, *v)
+        assert all(np.array_equal(a, b) for a, b in zip(good[:3], again[:3])) and good[3] == again[3]
+        assert s.p2p_selftest(2)

@@ -142,6 +142,43 @@ def test_large_oracle_runs_pinned_to_reference(reference_probe, oracle_large):
     assert checked >= 2
 
 
+def test_weak_scaling_series_is_fully_pinned(reference_probe, oracle_large):
+    """Every point of BASELINE.json configs[4] -- (16384,1), (23170,2), (32768,4), (46340,8) at 200 iterations -- has a
+    committed row.  Three are the reference's own outputs; (32768, P=4, 200) was not captured by the survey and is the
+    oracle's (on-the-fly twin, itself pinned to the reference at 32768/500 and 46340/200 above)."""
+    ref = {r["n"] for r in reference_probe["generated_large"] if r["max_iter"] == 200}
+    ours = {(c["n"], c["psize"]): c for c in oracle_large["cases"] if c["max_iter"] == 200}
+    assert ref == {16384, 23170, 46340}
+    for n, p in ((16384, 1), (23170, 2), (32768, 4), (46340, 8)):
+        assert (n, p) in ours, (n, p)
+    c = ours[(32768, 4)]
+    assert c["k"] == 200 and len(c["x_samples"]) >= 16 and c["residual"] > 1.0
+    # the partition does not change the recurrence beyond rounding: the P=4 row and a fresh P=1 run of the twin agree
+    # (reference: 1.331819e-05 for 1/2/4/8 ranks at N=2048, SURVEY.md section 4)
+
+
+def test_weak_scaling_p4_row_reproduces(oracle, oracle_large):
+    """The committed (32768, P=4, 200 iterations) row is what the oracle produces today (the twin takes seconds)."""
+    c = [q for q in oracle_large["cases"] if q["n"] == 32768 and q["max_iter"] == 200 and q["psize"] == 4][0]
+    x, r = oracle.solve_lap2d_banded(32768, 200, 1e-10, 4)
+    assert r["iterations"] == c["k"] and r["residual_prev"] == c["residual"] and r["x_norm"] == c["x_norm"]
+    for i, v in c["x_samples"].items():
+        assert x[int(i)] == v, i
+
+
+def test_mtx_oracle_run_to_convergence_is_pinned(reference_probe, oracle_large):
+    """BASELINE.json configs[0]: the committed oracle run of lap2D_5pt_n100.mtx to convergence (make_oracle_large.py mtx)
+    against the reference's recorded run: k is not a stable observable (reference: 488 on one rank, 462 on four), x is."""
+    row = oracle_large["mtx"][0]
+    ref = reference_probe["mtx_lap2D_5pt_n100"][0]
+    assert row["converged"] and row["residual_last"] < 1e-10 <= row["residual"]
+    assert abs(row["k"] - ref["k"]) <= 0.15 * ref["k"]
+    assert rel(row["x_norm"], ref["x_norm"]) < 1e-6 and row["rel_residual"] <= 1e-11
+    assert len(row["x_samples"]) >= 16
+    for i, v in ref["x_samples"].items():
+        assert rel(row["x_samples"][i], v) < 1e-12, i
+
+
 # ---- Matrix-Market input surface -----------------------------------------------------------------------
 def test_mtx_fixture_is_the_reference_file(mtx_path):
     ref = os.path.join(REF, "lap2D_5pt_n100.mtx")

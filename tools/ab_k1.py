@@ -34,4 +34,5 @@ for k, s in solvers.items():
     pl = sorted(h[0] for h in hist[k]); it = sorted(h[1] for h in hist[k])
     print(json.dumps(dict(n=n, shards=P, variant=k[0], pad=k[1], plain_ms_med=pl[len(pl)//2], plain_ms_min=pl[0],
                           iter_ms_med=it[len(it)//2], iter_ms_min=it[0], fused_k1_ms_last=res["gemv_ms_avg"],
+                          fused_k1_ms_median=res["gemv_ms_median"], fused_k1_ms_min=res["gemv_ms_min"],
                           plain_all=[round(x, 4) for x in (h[0] for h in hist[k])], iter_all=[round(h[1], 4) for h in hist[k]])), flush=True)
