@@ -593,6 +593,9 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
+    # cross-process device memory (the mailboxes, RCCL's own buffers) needs dmabuf IPC on this driver; keep the setting
+    # the image exports even if a launcher scrubbed the environment.  Before torch / HIP are loaded.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -59,6 +59,9 @@ int usage(const char *prog)
 
 int main(int argc, char **argv)
 {
+    // The ranks map each other's mailboxes with hipIpcOpenMemHandle: this host driver only supports dmabuf IPC, which the
+    // runtime uses when the legacy mode is switched off.  Must be in the environment before the first HIP call.
+    setenv("HSA_ENABLE_IPC_MODE_LEGACY", "0", 0);
     // ---- split options from the reference's positional arguments -------------------------------------
     std::vector<std::string> pos;
     int ngpu = 1, loopback = 0;
