@@ -112,28 +112,56 @@ __device__ __forceinline__ double sum_ranks(const double *__restrict__ gathered,
     return s;
 }
 
-// Tail of iteration k-1, evaluated redundantly (and identically) by every workgroup of K1(k).
-// r.r = fixed-order fold of K3's per-workgroup partials (the tail of the replicated-r segment): every
-// workgroup of every rank folds the same values the same way, so the break decision is the same everywhere,
-// and no in-kernel grid reduction (ticket + fences, ~4 us at the end of K3) is needed.  In K1 this sits
-// behind the first trip's HBM loads, which are already in flight.
+// Tail of iteration k-1, evaluated redundantly (and identically) by every WAVE of K1(k).
+// r.r = fixed-order fold of K3's per-workgroup partials (the tail of the replicated-r segment): every wave of every
+// workgroup of every rank folds the same values the same way (lane-strided sums, then the shuffle butterfly), so the
+// break decision is the same everywhere, and no in-kernel grid reduction (ticket + fences, ~4 us at the end of K3) is
+// needed.  No LDS and no workgroup barrier: on gfx9 a barrier's release fence drains vmcnt, i.e. it would wait for every
+// A load a kernel has already issued ahead of the head.  The head is cut in two so that a kernel can put its first
+// A loads between the halves: head_issue sends out the head's own loads (done, rsold, up to 256 partials), head_finish
+// consumes them -- loads return in order, so the wait in between covers the head's loads only.
 struct IterHead {
     double beta;
     bool stop;
 };
 
-template <int WAVES>
-__device__ __forceinline__ IterHead iteration_head(Scalars *sc, const SegView &sv, int k, double tol, double *lds)
+struct HeadLoads {
+    double rsold;
+    int done;
+    double a[4];
+};
+
+__device__ __forceinline__ HeadLoads head_issue(const Scalars *sc, const SegView &sv, int k)
+{
+    HeadLoads hl;
+    const int nparts = sv.S - sv.Sr, lane = threadIdx.x & 63;
+    const double *part = sv.base + sv.Sr;
+    hl.done = sc->done;                                  // converged earlier: the whole grid drains immediately
+    hl.rsold = sc->rs[(k > 0 ? k - 1 : 0) & 1];          // stored by the previous K1: independent of the fold
+    // unconditional loads (clamped index, value discarded by a select): a load behind a branch would make the number of
+    // loads in flight path dependent, and the compiler then waits for ALL of them (vmcnt(0)) instead of counting
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int t = lane + 64 * u;
+        const double val = part[t < nparts ? t : nparts - 1];
+        hl.a[u] = (t < nparts) ? val : 0.0;
+    }
+    return hl;
+}
+
+__device__ __forceinline__ IterHead head_finish(const HeadLoads &hl, Scalars *sc, const SegView &sv, int k, double tol)
 {
     IterHead h{0.0, false};
-    double v = 0.0;
-    const int nparts = sv.S - sv.Sr;
-    // rsold was stored by the previous K1: its load does not depend on the fold, so it goes out with the partials
-    // (one memory round trip for the whole head instead of two)
-    const double rsold = sc->rs[(k > 0 ? k - 1 : 0) & 1];
-    for (int t = threadIdx.x; t < nparts; t += WAVES * 64) v += sv.base[sv.Sr + t];
-    const double rsnew = block_sum<WAVES>(v, lds);                   // r.r over all rows, cg.cc:116-117 (k==0: cg.cc:91-92)
-    const bool first = (blockIdx.x == 0 && threadIdx.x == 0) && !sc->done;   // nothing is written once converged
+    const int nparts = sv.S - sv.Sr, lane = threadIdx.x & 63;
+    const double *part = sv.base + sv.Sr;
+    double v = (hl.a[0] + hl.a[1]) + (hl.a[2] + hl.a[3]);
+    for (int t = lane + 256; t < nparts; t += 256) {     // more than 256 partials: n > 65536
+        const double a0 = part[t], a1 = (t + 64 < nparts) ? part[t + 64] : 0.0;
+        const double a2 = (t + 128 < nparts) ? part[t + 128] : 0.0, a3 = (t + 192 < nparts) ? part[t + 192] : 0.0;
+        v += (a0 + a1) + (a2 + a3);
+    }
+    const double rsnew = wave_sum(v);                                // r.r over all rows, cg.cc:116-117 (k==0: cg.cc:91-92)
+    const bool first = (blockIdx.x == 0 && threadIdx.x == 0) && !hl.done;   // nothing is written once converged
     if (k == 0) {                                                    // p = r (cg.cc:85): beta = 0, p_old = 0
         if (first) { sc->rs[0] = rsnew; sc->rs[1] = rsnew; }
         return h;
@@ -144,8 +172,16 @@ __device__ __forceinline__ IterHead iteration_head(Scalars *sc, const SegView &s
         h.stop = true;
         return h;
     }
-    h.beta = rsnew / rsold;                                          // cg.cc:124
+    h.beta = rsnew / hl.rsold;                                       // cg.cc:124
     return h;
+}
+
+// Both halves back to back; *done = the flag as loaded.  All lanes of the wave must be active (shuffles).
+__device__ __forceinline__ IterHead iteration_head(Scalars *sc, const SegView &sv, int k, double tol, int *done)
+{
+    const HeadLoads hl = head_issue(sc, sv, k);
+    *done = hl.done;
+    return head_finish(hl, sc, sv, k, tol);
 }
 
 // p_new for the column pair (c, c+1); pad columns (>= n) stay exactly 0.
@@ -179,10 +215,12 @@ __device__ __forceinline__ d2 make_p(const SegView &sv, double beta, d2 p_old, i
 // ------------------------------------------------------------------------------------------------
 // The default shape (8,2) is held to 128 VGPRs = 4 workgroups per CU (the 4096-workgroup grid of N=32768 then runs in
 // exactly 4 rounds; at 3 per CU it needs 5.33 and loses ~1.2 %, measured).
-// LIGHT: for grids that are resident all at once at no more than two workgroups per CU (the shard of an 8-GPU run:
-// 4096 rows = 512 workgroups).  Such a launch has one round, so whatever a workgroup does before its first load and
-// after its last one is paid in full by the whole launch.  With 256 registers to spend, the first trip's loads go out
-// before the iteration head and the epilogue's two vector operands are fetched before the sweep.
+// LIGHT: for grids with few rounds (the shards of a multi-GPU run: 4096 rows = 512 ... 1024 workgroups).  Whatever a
+// workgroup does before its first load and after its last one is then paid nearly in full by the whole launch.  With
+// 256 registers to spend, the first trip's loads go out before the iteration head is folded and the epilogue's two
+// vector operands are fetched before the sweep.  (A two-trips-deep software pipeline of the sweep was built and
+// measured in round 2: no faster -- 157.0 us against 157.2 on the 4096 x 32768 shard -- and dropped again; what limits
+// this shape is the access pattern itself, tools/hbm_rows_bw.hip.)
 template <int R, int U, int WAVES, int MODE, bool LIGHT = false>
 __global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 1))) void k_gemv_colsplit(const double *__restrict__ A, long lda, int rows,
                                                                int row0_global, const double *__restrict__ v,
@@ -219,78 +257,85 @@ __global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 
     int step = 0;                        // index of the step this trip starts with
     int my_step = (int)blockIdx.x;       // next step whose p_new this workgroup stores
     double beta = 0.0;
+    double ep_v = 0.0, ep_r = 0.0;       // LIGHT: the epilogue's operands, fetched ahead of the sweep
 
-    d2 pv[U], rv2[U];
-    d2 av[U][R];
     // one trip = U steps: all vector and A loads first (R*U + 2U independent 16-B loads in flight per lane) ...
-    auto load_trip = [&](int cc) {
+    auto load_trip = [&](d2 (&pvx)[U], d2 (&rvx)[U], d2 (&avx)[U][R], int cc) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const unsigned off = (unsigned)(cc + u * kStep) * 8u;   // uniform base + 32-bit lane offset
-            pv[u] = *reinterpret_cast<const d2 *>(reinterpret_cast<const char *>(v) + off);
-            if constexpr (FUSED) rv2[u] = *reinterpret_cast<const d2 *>(reinterpret_cast<const char *>(rfull) + off);
+            pvx[u] = *reinterpret_cast<const d2 *>(reinterpret_cast<const char *>(v) + off);
+            if constexpr (FUSED) rvx[u] = *reinterpret_cast<const d2 *>(reinterpret_cast<const char *>(rfull) + off);
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int r = 0; r < R; ++r)
-                av[u][r] = load_a<NT>(reinterpret_cast<const double *>(a[r] + (unsigned)(cc + u * kStep) * 8u));
+                avx[u][r] = load_a<NT>(reinterpret_cast<const double *>(a[r] + (unsigned)(cc + u * kStep) * 8u));
     };
     // ... then p = r + beta p_old (cg.cc:127-129), its one store, and the FMAs.
-    auto compute_trip = [&](int cc, int st) {
+    auto compute_trip = [&](d2 (&pvx)[U], d2 (&rvx)[U], d2 (&avx)[U][R], int cc, int st) {
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             if constexpr (FUSED) {
-                pv[u].x = fma(beta, pv[u].x, rv2[u].x);
-                pv[u].y = fma(beta, pv[u].y, rv2[u].y);
+                pvx[u].x = fma(beta, pvx[u].x, rvx[u].x);
+                pvx[u].y = fma(beta, pvx[u].y, rvx[u].y);
                 if (st + u == my_step) {
-                    *reinterpret_cast<d2 *>(reinterpret_cast<char *>(p_new) + (unsigned)(cc + u * kStep) * 8u) = pv[u];
+                    *reinterpret_cast<d2 *>(reinterpret_cast<char *>(p_new) + (unsigned)(cc + u * kStep) * 8u) = pvx[u];
                     my_step += (int)gridDim.x;
                 }
             }
 #pragma unroll
             for (int r = 0; r < R; ++r) {
-                acc0[r] = fma(av[u][r].x, pv[u].x, acc0[r]);
-                acc1[r] = fma(av[u][r].y, pv[u].y, acc1[r]);
+                acc0[r] = fma(avx[u][r].x, pvx[u].x, acc0[r]);
+                acc1[r] = fma(avx[u][r].y, pvx[u].y, acc1[r]);
             }
         }
     };
+    auto full = [&](int cc) { return cc + (U - 1) * kStep < ncols; };   // a whole trip fits (per lane)
 
-    // The first trip's loads do not depend on the iteration head (done / r.r / beta): issue them first, so the
-    // head's dependent loads and its block reduction overlap the first HBM round trip instead of preceding it.
-    // Only for the light shapes: with R*U = 16 the 80 extra live registers push the kernel past 128 VGPRs
-    // (3 workgroups per CU: the 4096-workgroup grid of N=32768 then runs 5.33 rounds instead of 4, -1.2 %).
-    constexpr bool HOIST = LIGHT || R * U <= 8;
-    const bool first = HOIST && c + (U - 1) * kStep < ncols;
-    if (first) load_trip(c);
-    // LIGHT: the epilogue's operands (p_old and r of the workgroup's own rows) are fetched now instead of behind the sweep
-    double ep_v = 0.0, ep_r = 0.0;
-    if constexpr (LIGHT) {
-        if (w == 0 && lane < R && row0 + lane < rows) {
-            const int j = row0_global + (int)(row0 + lane);
+    d2 pv[U], rv2[U];
+    d2 av[U][R];
+    {
+        // The first trip's loads do not depend on the iteration head (done / r.r / beta).  Issue order: the head's own
+        // loads, (LIGHT) the epilogue's two operands, the first trip -- then the head is finished while the first trip
+        // is in flight: loads return in order, so the wait in front of the fold covers the head's loads only.  Every one
+        // of these loads is unconditional for the lanes that have a whole first trip (a load behind a divergent branch
+        // makes the count path dependent and the compiler then drains everything).
+        // Hoisting needs the trip's registers during the head: only for the light shapes (with R*U = 16 the 80 extra
+        // live registers push the 4-per-CU kernel past 128 VGPRs: the 4096-workgroup grid of N=32768 then runs 5.33
+        // rounds instead of 4, -1.2 %) and for the one-round form, which has 256 registers.
+        constexpr bool HOIST = LIGHT || R * U <= 8;
+        HeadLoads hl{};
+        if constexpr (FUSED) hl = head_issue(sc, sv, k);
+        if constexpr (LIGHT) {
+            long er = row0 + (lane & (R - 1));
+            if (er > rows - 1) er = rows - 1;
+            if (er < 0) er = 0;
+            const int j = row0_global + (int)er;
             ep_v = v[j];
             if constexpr (FUSED) ep_r = seg_load(sv, j);
         }
-    }
-    if constexpr (FUSED) {
-        __shared__ double head_lds[WAVES];
-        const int done = sc->done;       // converged earlier: the whole grid drains immediately
-        const IterHead h = iteration_head<WAVES>(sc, sv, k, tol, head_lds);
-        if (done || h.stop) return;
-        beta = h.beta;
-    }
-    // Keep all loads of a trip in flight: without this fence hipcc's occupancy-driven scheduler
-    // re-serialises them as load / s_waitcnt vmcnt(0) / fma pairs (measured in the .s).
-    __builtin_amdgcn_sched_barrier(0);
-    if (first) {
-        compute_trip(c, step);
-        c += U * kStep;
-        step += U;
-    }
-    for (; c + (U - 1) * kStep < ncols; c += U * kStep, step += U) {
-        load_trip(c);
+        const bool first = HOIST && full(c);
+        if (first) load_trip(pv, rv2, av, c);
+        if constexpr (FUSED) {
+            const IterHead h = head_finish(hl, sc, sv, k, tol);
+            if (hl.done || h.stop) return;
+            beta = h.beta;
+        }
+        // Keep all loads of a trip in flight: without this fence hipcc's occupancy-driven scheduler
+        // re-serialises them as load / s_waitcnt vmcnt(0) / fma pairs (measured in the .s).
         __builtin_amdgcn_sched_barrier(0);
-        compute_trip(c, step);
+        if (first) {
+            compute_trip(pv, rv2, av, c, step);
+            c += U * kStep;
+            step += U;
+        }
+        for (; full(c); c += U * kStep, step += U) {
+            load_trip(pv, rv2, av, c);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_trip(pv, rv2, av, c, step);
+        }
     }
     for (; c < ncols; c += kStep, ++step) {   // remaining single steps (lda is even, so c+1 < lda)
         d2 p1 = *reinterpret_cast<const d2 *>(v + c);
@@ -327,6 +372,7 @@ __global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 
             if (row < rows) {
                 Ap[row] = s;
                 const int j = row0_global + (int)row;
+                // (LIGHT: lane < R holds the operands of row row0 + lane, fetched ahead of the sweep)
                 double pl = LIGHT ? ep_v : v[j];
                 if constexpr (FUSED) pl = fma(beta, pl, LIGHT ? ep_r : seg_load(sv, j));   // same bits as the stored p_new[j]
                 d = pl * s;                                                 // cg.cc:105
@@ -359,9 +405,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_ldsp(const double *__restri
     constexpr bool NT = true;
     double beta = 0.0;
     if constexpr (FUSED) {
-        __shared__ double head_lds[WAVES];
-        const int done = sc->done;
-        const IterHead h = iteration_head<WAVES>(sc, sv, k, tol, head_lds);
+        int done;
+        const IterHead h = iteration_head(sc, sv, k, tol, &done);
         if (done || h.stop) return;
         beta = h.beta;
     }
@@ -535,8 +580,8 @@ __global__ __launch_bounds__(256) void k_update_xr(int n, int rows, int row0, co
 // same bits), or, for k == 0, the rsold of cg.cc:91-92.
 __global__ __launch_bounds__(256) void k_close_iteration(Scalars *sc, SegView sv, int k, double tol)
 {
-    __shared__ double lds[4];
-    (void)iteration_head<4>(sc, sv, k, tol, lds);
+    int done;
+    (void)iteration_head(sc, sv, k, tol, &done);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -703,8 +748,8 @@ __global__ __launch_bounds__(256) void k_spmv_dia(DiaView dv, int rows, int row0
     const double *rfull = sv.base;   // FUSED: the replicated r, zero padded up to lda
     double beta = 0.0;
     if constexpr (FUSED) {
-        const int done = sc->done;
-        const IterHead h = iteration_head<4>(sc, sv, k, tol, lds);
+        int done;
+        const IterHead h = iteration_head(sc, sv, k, tol, &done);
         if (done || h.stop) return;
         beta = h.beta;
         // p_new = r + beta p_old (cg.cc:127-129) for the columns that are not rows of this shard (other ranks' rows
@@ -1175,7 +1220,8 @@ hipError_t dispatch_gemv(const GemvPlan &pl, const GemvArgs &g, hipStream_t s)
         if (pl.R == 8 && pl.U == 2) return launch_light<8, 2, MODE>(pl, g, s);
         if (pl.R == 8 && pl.U == 4) return launch_light<8, 4, MODE>(pl, g, s);
         if (pl.R == 4 && pl.U == 4) return launch_light<4, 4, MODE>(pl, g, s);
-        if (pl.R == 4 && pl.U == 8) return launch_light<4, 8, MODE>(pl, g, s);
+        if (pl.R == 2 && pl.U == 8) return launch_light<2, 8, MODE>(pl, g, s);
+        if (pl.R == 16 && pl.U == 1) return launch_light<16, 1, MODE>(pl, g, s);
         return hipErrorInvalidValue;
     }
 #define CGX_SHAPE(r, u) \

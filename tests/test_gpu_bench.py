@@ -125,3 +125,16 @@ def test_bench_watchdog_prints_a_failure_line(gpu_pkg):
     d = one_line(r.stdout)
     assert d["value"] is None and d["error"]["kind"] == "watchdog"
     assert r.returncode == 3
+
+
+def test_bench_auto_transport_one_rank_under_the_launcher(gpu_pkg):
+    """The driver's multi-GPU launch shape with one rank: nccl control plane (CUDA control tensors), all three transports
+    built, pre-warmed and calibrated against each other, the fastest one timed."""
+    r = torchrun(1, 29724, ["--steps", "20", "--warmup", "5", "--matrix-size", "8192", "--no-cpu-baseline"])
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    d = one_line(r.stdout)
+    c = d["config"]
+    assert set(c["transport_calibration_ms_per_iteration"]) == {"p2p", "p2p-sep", "rccl"}
+    assert c["transport"] in ("p2p", "p2p-sep", "rccl") and c["transport_notes"] is None
+    assert c["transport"] == min(c["transport_calibration_ms_per_iteration"], key=c["transport_calibration_ms_per_iteration"].get)
+    assert d["value"] > 0 and d["roofline"]["consistency"] == "ok" and d["roofline"]["launches_timed"] == 19

@@ -54,7 +54,7 @@ def test_generator_bit_exact(gpu_pkg, oracle, n, mode, p):
 
 # ---- K1 ------------------------------------------------------------------------------------------------
 VARIANTS = [0, 10821, 10820, 10811, 10441, 10421, 10241, 10281, 10181, 11611, 20821, 20811, 20441, 20421, 20241, 20281, 20181,
-            10822, 10842, 10442, 10482]   # last digit 2: the one-round form of the column-split kernel (shards of an 8-GPU run)
+            10822, 10842, 10442, 10282, 11612]   # last digit 2: the one-round form of the column-split kernel (shards of an 8-GPU run)
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -68,6 +68,23 @@ def test_gemv_generated(gpu_pkg, oracle, n, variant):
     yo = oracle.gemv(oracle.generate_lap2d(n), p)
     assert np.max(np.abs(y - yo)) <= 2e-14 * max(np.max(np.abs(yo)), 1e-300)
     assert abs(pap - oracle.dot(p, yo)) <= 1e-12 * np.sum(np.abs(p * yo))
+
+
+@pytest.mark.parametrize("variant", [10822, 10842, 10442, 10282, 11612])
+@pytest.mark.parametrize("n", [1023, 2047, 3000, 5200])
+def test_gemv_one_round_form_trip_counts(gpu_pkg, oracle, n, variant):
+    """The one-round form (first trip issued ahead of the iteration head) on dense random A, sizes with and without a
+    whole first trip for every lane."""
+    rng = np.random.default_rng(n + variant)
+    A = rng.standard_normal((n, n))
+    p = rng.standard_normal(n)
+    with gpu_pkg.CGSolver(gemv_variant=variant) as s:
+        s.set_matrix_dense(A)
+        y, pap = s.probe_gemv(p)
+    yo = oracle.gemv(A, p)
+    scale = np.abs(A) @ np.abs(p)
+    assert np.all(np.abs(y - yo) <= 4e-16 * np.sqrt(n) * scale + 1e-300)
+    assert abs(pap - oracle.dot(p, yo)) <= 1e-13 * np.sum(np.abs(p * yo))
 
 
 @pytest.mark.parametrize("variant", [0, 10821, 10441, 20821, 20441, 10822, 10842])
@@ -201,7 +218,7 @@ def test_alpha_safeguard_keeps_a_nan_like_std_max(gpu_pkg, oracle):
     (64, 10, None, 1, 0), (1000, 100, None, 1, 0), (1024, 100, None, 1, 20441), (2048, 200, None, 1, 0),
     (2048, 200, 1, 2, 0), (2048, 200, 1, 4, 0), (2048, 200, 1, 8, 10821), (1000, 150, 1, 3, 0), (1000, 150, 1, 7, 20441),
     (4096, 50, None, 1, 0), (4096, 200, 1, 8, 0),
-    (2048, 200, 1, 8, 10822), (1000, 150, 1, 3, 10842), (4096, 50, None, 1, 10822), (1024, 100, None, 1, 10482),
+    (2048, 200, 1, 8, 10822), (1000, 150, 1, 3, 10842), (4096, 50, None, 1, 10822), (1024, 100, None, 1, 10282), (3000, 60, 1, 2, 11612),
 ])
 def test_fixed_iteration_solve_matches_oracle(gpu_pkg, oracle, n, max_iter, mode, p, variant):
     with make(gpu_pkg, n, mode, p, variant, max_iter) as s:
@@ -522,7 +539,7 @@ def test_config2_n10000_converges_like_reference(gpu_pkg, reference_probe):
 
 
 @pytest.mark.parametrize("mode,p,variant", [(None, 1, 0), (1, 2, 0), (1, 4, 0), (1, 8, 0), (None, 1, 20441), (1, 8, 20241),
-                                            (1, 8, 10822), (1, 8, 10842)])
+                                            (1, 8, 10822), (1, 8, 10442)])
 def test_config3_n32768_500_iterations(gpu_pkg, reference_probe, mode, p, variant):
     """The roofline point and (as 2/4/8 logical row blocks on one GPU) the strong-scaling partitions, with the default
     K1 and with the LDS-staged variant."""

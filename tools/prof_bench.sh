@@ -1,7 +1,7 @@
 #!/bin/bash
 # the bench line and the rocprofv3 kernel stats of the same program (profiles/r01_bench_*, r01_rocprofv3_kernel_stats_*)
 set -e
-R=$PWD
+R=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p $R/gpurun_out
 python3 $R/bench.py > $R/gpurun_out/bench_default.json 2> $R/gpurun_out/bench_default.err
 cd /tmp && export TMPDIR=/tmp

@@ -2,7 +2,7 @@
 # rocprofv3 kernel stats of the iteration on the shard shapes of N=32768 (P logical row blocks on one GPU) and of the
 # one-rank P2P iteration (K3 with the exchange inside): the evidence behind DESIGN.md section 6's P=8 estimate.
 set -e
-R=$PWD
+R=$(cd "$(dirname "$0")/.." && pwd)
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $R/gpurun_out/shards
 for P in 8 4 2; do
