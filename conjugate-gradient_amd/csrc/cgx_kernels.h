@@ -52,11 +52,13 @@ struct GemvPlan {
     int nt;          // non-temporal loads of A
     int grid;        // workgroups
     int rows_per_wg;
+    int ncols;       // columns the sweep covers: the logical n rounded up to even (16-B pieces); the pad columns up to the
+                     // pitch are zero in A and in every vector and are never touched
     int light;       // variant 1: the one-round form (grid <= 512 workgroups, at most two per CU; see k_gemv_colsplit)
 };
 
-// Choose the K1 shape for a shard of `rows` x `ncols` (variant 0 = default).
-GemvPlan plan_gemv(int variant, int rows, int ncols);
+// Choose the K1 shape for a shard of `rows` x `n` held at pitch `lda` (variant 0 = default).
+GemvPlan plan_gemv(int variant, int rows, int n, long lda);
 
 // K1, plain form: Ap = A[rows x lda] * v ; partials[wg] = sum over the workgroup's rows of v_local[i]*Ap[i].
 // Used for the initial residual (cg.cc:79-81), the DEBUG verification (cg.cc:146-147) and the probes.

@@ -56,6 +56,62 @@ __device__ __forceinline__ double wave_sum(double v)
     return v;   // every lane holds the total
 }
 
+// Sums of R independent per-lane values over the 64 lanes at once (R a power of two).  Instead of R butterflies of six
+// exchanges each, the lanes first split the rows among themselves: at every halving step a lane keeps half of its rows
+// and hands the other half to its partner, so the exchanges go R/2 + R/4 + ... + 1, and the rest of the butterfly runs
+// on ONE value.  R = 8: 10 exchanges instead of 48.  Afterwards v[0] of lane L is the total of row L >> (6 - log2 R)
+// (every lane of that group holds it).  Fixed order => bitwise reproducible for a given shape.
+// v + (v of the partner lane), the partner given by a DPP control word: no LDS crossbar, a few cycles instead of a
+// ds_bpermute round trip.  0xB1 / 0x4E: quad_perm = lane ^ 1 / lane ^ 2.  0x141 / 0x140: row_half_mirror / row_mirror
+// pair lane i with 7 - i of its 8 / 15 - i of its 16 lanes -- as good as lane ^ 4 / lane ^ 8 for a sum once the lower
+// levels have made the lanes of each quad / each 8 hold the same value (which is the order they are used in below).
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, false);
+    return v + __hiloint2double(hi, lo);
+}
+
+// Total of one value over groups of SPAN consecutive lanes (SPAN a power of two <= 64), every lane of the group gets it:
+// levels 1, 2, 4, 8 by DPP, 16 and 32 by ds_bpermute.
+template <int SPAN>
+__device__ __forceinline__ double group_sum(double v)
+{
+    if constexpr (SPAN > 32) v += __shfl_xor(v, 32, 64);
+    if constexpr (SPAN > 16) v += __shfl_xor(v, 16, 64);
+    if constexpr (SPAN > 1) v = dpp_add<0xB1>(v);
+    if constexpr (SPAN > 2) v = dpp_add<0x4E>(v);
+    if constexpr (SPAN > 4) v = dpp_add<0x141>(v);
+    if constexpr (SPAN > 8) v = dpp_add<0x140>(v);
+    return v;
+}
+
+template <int R, int N, int WIDTH>
+__device__ __forceinline__ void wave_sum_rows_step(double (&v)[R], int lane)
+{
+    if constexpr (N > 1) {
+        const bool upper = (lane & WIDTH) != 0;
+#pragma unroll
+        for (int i = 0; i < N / 2; ++i) {
+            const double send = upper ? v[i] : v[i + N / 2];
+            const double keep = upper ? v[i + N / 2] : v[i];
+            v[i] = keep + __shfl_xor(send, WIDTH, 64);
+        }
+        wave_sum_rows_step<R, N / 2, WIDTH / 2>(v, lane);
+    } else {
+        v[0] = group_sum<2 * WIDTH>(v[0]);   // the lanes that still differ: groups of 2*WIDTH = 64/R
+    }
+}
+
+template <int R>
+__device__ __forceinline__ int wave_sum_rows(double (&v)[R], int lane)
+{
+    static_assert(R >= 1 && R <= 64 && (R & (R - 1)) == 0, "rows per workgroup must be a power of two");
+    wave_sum_rows_step<R, R, 32>(v, lane);
+    return lane / (64 / R);   // the row this lane holds: its top log2(R) lane bits
+}
+
 template <int WAVES>
 __device__ __forceinline__ double block_sum(double v, double *lds /* >= WAVES doubles */)
 {
@@ -222,7 +278,7 @@ __device__ __forceinline__ d2 make_p(const SegView &sv, double beta, d2 p_old, i
 // measured in round 2: no faster -- 157.0 us against 157.2 on the 4096 x 32768 shard -- and dropped again; what limits
 // this shape is the access pattern itself, tools/hbm_rows_bw.hip.)
 template <int R, int U, int WAVES, int MODE, bool LIGHT = false>
-__global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 1))) void k_gemv_colsplit(const double *__restrict__ A, long lda, int rows,
+__global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 1))) void k_gemv_colsplit(const double *__restrict__ A, long lda, int ncols, int rows,
                                                                int row0_global, const double *__restrict__ v,
                                                                double *__restrict__ p_new, SegView sv,
                                                                double *__restrict__ Ap, double *partials,
@@ -235,7 +291,8 @@ __global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     const long row0 = (long)blockIdx.x * R;
-    const int ncols = (int)lda;   // pad columns hold zeros in A and in the vectors
+    // ncols = n rounded up to even: the pad columns up to the pitch hold zeros in A and in the vectors and are skipped
+    // (sweeping them cost wave 0 of every workgroup one more, fully exposed, memory round trip at the end of its rows)
     const double *rfull = sv.base;   // FUSED: the replicated r, contiguous and zero padded up to lda
 
     // Row bases are workgroup-uniform (SGPR pairs); the lane's position is ONE 32-bit byte offset, so each A load
@@ -337,7 +394,7 @@ __global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 
             compute_trip(pv, rv2, av, c, step);
         }
     }
-    for (; c < ncols; c += kStep, ++step) {   // remaining single steps (lda is even, so c+1 < lda)
+    for (; c < ncols; c += kStep, ++step) {   // remaining single steps (ncols is even, so c+1 < lda)
         d2 p1 = *reinterpret_cast<const d2 *>(v + c);
         if constexpr (FUSED) {
             const d2 r1 = *reinterpret_cast<const d2 *>(rfull + c);
@@ -356,10 +413,13 @@ __global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 
         }
     }
 
+    // the wave's R row sums: one shared reduction (see wave_sum_rows), not R butterflies -- in a launch with one round
+    // of workgroups the epilogue of every workgroup is on the launch's critical path
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-        double s = wave_sum(acc0[r] + acc1[r]);
-        if (lane == 0) red[w][r] = s;
+    for (int r = 0; r < R; ++r) acc0[r] += acc1[r];
+    {
+        const int myrow = wave_sum_rows<R>(acc0, lane);
+        if ((lane & (64 / R - 1)) == 0) red[w][myrow] = acc0[0];
     }
     __syncthreads();
     double d = 0.0;
@@ -378,7 +438,7 @@ __global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 
                 d = pl * s;                                                 // cg.cc:105
             }
         }
-        d = wave_sum(d);
+        d = group_sum<(R < 64 ? R : 64)>(d);   // only lanes 0..R-1 hold a term
         // One partial per workgroup; K3 folds all of them (all ranks') in a fixed order.  No ticket here:
         // 4096 workgroups taking a returning atomic on one word cost 3-10 % of K1 (measured).
         if (lane == 0) partials[blockIdx.x] = d;
@@ -1132,9 +1192,12 @@ void seg_finalize(SegView *sv)
     sv->div_shift = s - 1;
 }
 
-GemvPlan plan_gemv(int variant, int rows, int ncols)
+GemvPlan plan_gemv(int variant, int rows, int n, long lda)
 {
     GemvPlan pl{};
+    const int ncols = (int)lda;
+    pl.ncols = (n + 1) & ~1;
+    if (pl.ncols > ncols) pl.ncols = ncols;
     pl.waves = 4;
     if (variant <= 0) {
         // default: column-split; the shape comes from measurements on MI355X (profiles/r01_k1_*, tools/ab_k1.py,
@@ -1201,7 +1264,7 @@ hipError_t launch_shape(const GemvPlan &pl, const GemvArgs &g, hipStream_t s)
                               g.row0, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol);
     else
         hipExtLaunchKernelGGL((k_gemv_colsplit<R, U, 4, MODE>), dim3(pl.grid), dim3(256), 0, s, g.e0, g.e1, 0, g.A, g.lda,
-                              g.rows, g.row0, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol);
+                              pl.ncols, g.rows, g.row0, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol);
     return hipGetLastError();
 }
 
@@ -1209,7 +1272,7 @@ template <int R, int U, int MODE>
 hipError_t launch_light(const GemvPlan &pl, const GemvArgs &g, hipStream_t s)
 {
     hipExtLaunchKernelGGL((k_gemv_colsplit<R, U, 4, MODE, true>), dim3(pl.grid), dim3(256), 0, s, g.e0, g.e1, 0, g.A, g.lda,
-                          g.rows, g.row0, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol);
+                          pl.ncols, g.rows, g.row0, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol);
     return hipGetLastError();
 }
 

@@ -118,7 +118,7 @@ cgx_status cgx_probe_vector_ops(cgx_ctx *ctx, int n, double alpha, double beta, 
     HIP_TRY(ctx, hipMemcpyAsync(&dsc->rs[0], &one, sizeof(double), hipMemcpyHostToDevice, st));
     HIP_TRY(ctx, hipMemsetAsync(drb + lda, 0, (size_t)grid * sizeof(double), st));
     HIP_TRY(ctx, hipMemcpyAsync(drb + lda, &beta, sizeof(double), hipMemcpyHostToDevice, st));
-    cgx::GemvPlan plan = cgx::plan_gemv(ctx->cfg.gemv_variant, 1, (int)lda);
+    cgx::GemvPlan plan = cgx::plan_gemv(ctx->cfg.gemv_variant, 1, n, lda);
     HIP_TRY(ctx, cgx::launch_gemv_fused(plan, dA, lda, 1, 0, dp0, dp1, rv, dAp1, dAp1 + 8, dsc, 1, -1.0 /* never converges */, st));
     HIP_TRY(ctx, hipMemcpyAsync(p, dp1, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
