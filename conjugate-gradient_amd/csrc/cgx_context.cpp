@@ -133,7 +133,7 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
         const char *e = getenv("CGX_GEMV_VARIANT");
         if (e) variant = atoi(e);
     }
-    auto plan_for = [&](int rows) { return ctx->banded ? cgx::plan_dia(rows) : cgx::plan_gemv(variant, rows, ctx->n, ctx->lda); };
+    auto plan_for = [&](int rows) { return ctx->banded ? cgx::plan_dia(rows, variant) : cgx::plan_gemv(variant, rows, ctx->n, ctx->lda); };
     ctx->npart = 1;
     for (int q = 0; q < ctx->nranks; ++q) ctx->npart = std::max(ctx->npart, plan_for(ctx->num_rows[q]).grid);
     if (ctx->cfg.comm_mode == CGX_COMM_P2P && n > 256 * cgx::kMaxVectorGrid)

@@ -128,12 +128,13 @@ struct DiaView {
     int ndiag;
     int off[kMaxDiags];
 };
-GemvPlan plan_dia(int rows);   // variant 3, grid = min(ceil(rows/512), 2048)
+GemvPlan plan_dia(int rows, int variant = 0);   // variant 3, grid = min(ceil(rows/512), 2048); plan.light = LDS-window form
+                                                // (cfg variant 30001 / 30002 force the direct / the window form)
 
 // K1 on banded storage: same contract as launch_gemv_plain / launch_gemv_fused (same iteration head, same p_new
 // = r + beta p_old, same one partial per workgroup), 8*(rows*ndiag) bytes of matrix instead of 8*rows*n.
-hipError_t launch_spmv_dia_plain(const GemvPlan &plan, const DiaView &dv, int rows, int row0, int n, const double *v_full,
-                                 double *Ap, double *partials, Scalars *sc, hipStream_t s);
+hipError_t launch_spmv_dia_plain(const GemvPlan &plan, const DiaView &dv, int rows, int row0, int n, long lda,
+                                 const double *v_full, double *Ap, double *partials, Scalars *sc, hipStream_t s);
 hipError_t launch_spmv_dia_fused(const GemvPlan &plan, const DiaView &dv, int rows, int row0, int n, long lda,
                                  const double *p_old, double *p_new, SegView seg, double *Ap, double *partials,
                                  Scalars *sc, int k, double tol, hipStream_t s, hipEvent_t e_start = nullptr,

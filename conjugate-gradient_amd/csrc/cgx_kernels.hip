@@ -876,6 +876,139 @@ __global__ __launch_bounds__(256) void k_spmv_dia(DiaView dv, int rows, int row0
     if (threadIdx.x == 0) partials[blockIdx.x] = d;
 }
 
+// ------------------------------------------------------------------------------------------------
+// K1b with the vector staged in LDS windows (round 2).  The direct form above loads, per pair of rows and per diagonal,
+// 16 B of p_old and 16 B of r straight from L2 (neighbouring threads overlap almost completely: 2.0 x the minimal number
+// of L2 requests, measured) and forms p = r + beta p_old once per use.  Here a workgroup owns a tile of 512 consecutive
+// rows; diagonals whose offsets lie within kWinGap of each other share a WINDOW of columns
+//     [tile + lo, tile + 512 + hi)                      (for the 5-point inputs: three windows, -inc-1 | -1,0,+1 | +inc+1)
+// and each window is fetched ONCE per tile with aligned 16-B loads, combined (p = fma(beta, p_old, r), cg.cc:127-129)
+// on its way into LDS and read back by every row as two neighbouring doubles.  The diagonal values of the tile are
+// requested before the staging so that they are in flight behind it.  Same arithmetic, same order of the row sums, same
+// bits as the direct form.
+// ------------------------------------------------------------------------------------------------
+constexpr int kWinGap = 256;        // widest spread of offsets inside one window
+constexpr int kMaxWindows = 8;      // more windows than that: the direct form runs
+struct DiaWindows {
+    int nwin;
+    int start[kMaxWindows];         // first column of the window relative to the tile's first row (even + parity fix)
+    int len[kMaxWindows];           // doubles (even)
+    int base[kMaxWindows];          // position of the window in LDS (doubles, even)
+    short idx[kMaxDiags];           // per diagonal: LDS index of column (row + off) for the tile's first row
+    int total;                      // doubles of LDS in all
+};
+
+template <int MODE, int CH>
+__global__ __launch_bounds__(256) void k_spmv_dia_lds(DiaView dv, DiaWindows dw, int rows, int row0_global, int n, long lda,
+                                                       const double *__restrict__ v, double *__restrict__ p_new, SegView sv,
+                                                       double *__restrict__ Ap, double *__restrict__ partials, Scalars *sc,
+                                                       int k, double tol)
+{
+    constexpr bool FUSED = MODE != kPlain;
+    extern __shared__ __attribute__((aligned(16))) double win[];
+    __shared__ double lds[4];
+    const double *rfull = sv.base;   // FUSED: the replicated r, zero padded up to lda
+    double beta = 0.0;
+    if constexpr (FUSED) {
+        int done;
+        const IterHead h = iteration_head(sc, sv, k, tol, &done);
+        if (done || h.stop) return;
+        beta = h.beta;
+        // p_new for the columns that are not rows of this shard: as in the direct form
+        const long before = row0_global, after = lda - ((long)row0_global + rows);
+        for (long c = (long)blockIdx.x * 256 + threadIdx.x; c < before + after; c += (long)gridDim.x * 256) {
+            const long cc = c < before ? c : c - before + row0_global + rows;
+            p_new[cc] = fma(beta, v[cc], rfull[cc]);
+        }
+    }
+    const int tid = threadIdx.x;
+    const int ntiles = (rows + 511) / 512;
+    double d = 0.0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long i = (long)tile * 512 + 2 * tid;       // this thread's two local rows i, i+1 (may lie behind the block)
+        const int g0 = row0_global + tile * 512;          // global index of the tile's first row
+        const bool live = i < rows;
+        const long il = live ? i : 0;                     // behind the block: re-read row 0, nothing is stored
+        const int g = row0_global + (int)il;
+        // the tile's diagonal values and own-row vector pieces first: in flight while the windows are staged
+        d2 a[CH];
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            const int t = u < dv.ndiag ? u : dv.ndiag - 1;
+            a[u] = load_a<true>(dv.vals + t * dv.ld + il);
+        }
+        const d2u pv = *reinterpret_cast<const d2u *>(v + g);
+        d2u pr{0.0, 0.0};
+        if constexpr (FUSED) pr = *reinterpret_cast<const d2u *>(rfull + g);
+        // stage the windows: aligned pairs of columns, clamped at the ends of the vectors
+        for (int w = 0; w < dw.nwin; ++w) {
+            const int c0 = g0 + dw.start[w];              // even
+            double *dst = win + dw.base[w];
+            for (int q = tid; q < dw.len[w] / 2; q += 256) {
+                const int c = c0 + 2 * q;
+                double x0 = 0.0, x1 = 0.0, r0 = 0.0, r1 = 0.0;
+                if (c >= 0 && c + 1 < lda) {
+                    const d2 xv = *reinterpret_cast<const d2 *>(v + c);
+                    x0 = xv.x;
+                    x1 = xv.y;
+                    if constexpr (FUSED) {
+                        const d2 rv = *reinterpret_cast<const d2 *>(rfull + c);
+                        r0 = rv.x;
+                        r1 = rv.y;
+                    }
+                } else {                                   // first / last tile only; a column outside [0,n) meets a stored 0
+                    if (c >= 0 && c < lda) { x0 = v[c]; if constexpr (FUSED) r0 = rfull[c]; }
+                    if (c + 1 >= 0 && c + 1 < lda) { x1 = v[c + 1]; if constexpr (FUSED) r1 = rfull[c + 1]; }
+                }
+                if constexpr (FUSED) {
+                    x0 = fma(beta, x0, r0);                // same bits as the stored p_new[c]
+                    x1 = fma(beta, x1, r1);
+                }
+                d2 o;
+                o.x = x0;
+                o.y = x1;
+                *reinterpret_cast<d2 *>(dst + 2 * q) = o;
+            }
+        }
+        __syncthreads();
+        double acc0 = 0.0, acc1 = 0.0;
+        for (int t0 = 0; t0 < dv.ndiag; t0 += CH) {
+            if (t0 > 0) {                                  // more than CH diagonals: the next chunk's values
+#pragma unroll
+                for (int u = 0; u < CH; ++u) {
+                    const int t = t0 + u < dv.ndiag ? t0 + u : dv.ndiag - 1;
+                    a[u] = load_a<true>(dv.vals + t * dv.ld + il);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                if (t0 + u < dv.ndiag) {
+                    const double *q = win + dw.idx[t0 + u] + 2 * tid;
+                    acc0 = fma(a[u].x, q[0], acc0);        // cg.cc:100-102, ascending columns
+                    acc1 = fma(a[u].y, q[1], acc1);
+                }
+            }
+        }
+        if (live) {
+            double p0 = pv.x, p1 = pv.y;
+            if constexpr (FUSED) {
+                p0 = fma(beta, p0, pr.x);
+                p1 = fma(beta, p1, pr.y);
+                *reinterpret_cast<d2u *>(p_new + g) = d2u{p0, p1};
+            }
+            d2 out;
+            out.x = acc0;
+            out.y = acc1;
+            *reinterpret_cast<d2 *>(Ap + i) = out;
+            d = fma(p0, acc0, d);                          // cg.cc:105
+            d = fma(p1, acc1, d);
+        }
+        __syncthreads();                                   // the windows are free for the next tile
+    }
+    d = block_sum<4>(d, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = d;
+}
+
 // generate_lap2d_matrix (cg.cc:159-188) straight into banded storage.
 __global__ __launch_bounds__(256) void k_dia_generate_lap2d(double *__restrict__ vals, DiaView dv, int size, int row0,
                                                              int rows, int inc)
@@ -1336,7 +1469,7 @@ hipError_t launch_update_xr(int n, int rows, int row0, const double *p_new, SegV
     return hipGetLastError();
 }
 
-GemvPlan plan_dia(int rows)
+GemvPlan plan_dia(int rows, int variant)
 {
     GemvPlan pl{};
     pl.variant = 3;
@@ -1346,6 +1479,11 @@ GemvPlan plan_dia(int rows)
     pl.rows_per_wg = 512;   // two consecutive rows per thread
     pl.grid = rows > 0 ? ceil_div(rows, 512) : 1;
     if (pl.grid > 2048) pl.grid = 2048;   // above that the workgroups stride: K3 folds at most 2048 partials per rank (1024..8192: same speed, measured)
+    // light = the LDS-window form of K1b.  30001 / 30002 force the direct / the window form.  Default by size, from
+    // tools/banded_bench.py: the window form is slower up to 2^24 rows (258 against 246 us there: two barriers per
+    // tile, and the direct form's overlapping vector loads were never the limiter -- both sit at ~90 % of what the
+    // memory system gives this mix of 7 read and 2 write streams, tools/hbm_mix_bw.hip) and 5 % faster at 2^26.
+    pl.light = variant == 30002 ? 1 : (variant == 30001 ? 0 : (rows >= (1 << 25) ? 1 : 0));
     return pl;
 }
 
@@ -1365,9 +1503,44 @@ struct DiaArgs {
     hipEvent_t e0 = nullptr, e1 = nullptr;
 };
 
+// Group the (ascending) offsets into windows; false if they do not fit kMaxWindows.  parity = parity of the first
+// global row of a tile (tiles start at multiples of 512 behind row0): window starts are made even in GLOBAL columns.
+bool make_windows(const DiaView &dv, int row0_parity, DiaWindows *dw)
+{
+    dw->nwin = 0;
+    dw->total = 0;
+    int t = 0;
+    while (t < dv.ndiag) {
+        if (dw->nwin == kMaxWindows) return false;
+        const int lo = dv.off[t];
+        int hi = lo, t1 = t;
+        while (t1 + 1 < dv.ndiag && dv.off[t1 + 1] - lo <= kWinGap) hi = dv.off[++t1];
+        const int w = dw->nwin++;
+        int start = lo;
+        if (((start + row0_parity) & 1) != 0) --start;           // even global column
+        int len = 512 + hi - start;                               // rows i, i+1 <= tile + 511, columns up to tile + 511 + hi
+        len = (len + 1) & ~1;
+        dw->start[w] = start;
+        dw->len[w] = len;
+        dw->base[w] = dw->total;
+        dw->total += len;
+        for (int u = t; u <= t1; ++u) dw->idx[u] = (short)(dw->base[w] + dv.off[u] - start);
+        t = t1 + 1;
+    }
+    return dw->total * 8 <= 60 * 1024;
+}
+
 template <int MODE, int CH>
 hipError_t launch_dia_chunk(const GemvPlan &pl, const DiaArgs &g, hipStream_t s)
 {
+    if (pl.light) {   // LDS windows
+        DiaWindows dw;
+        if (make_windows(g.dv, g.row0 & 1, &dw)) {
+            hipExtLaunchKernelGGL((k_spmv_dia_lds<MODE, CH>), dim3(pl.grid), dim3(256), (unsigned)dw.total * 8u, s, g.e0, g.e1, 0,
+                                  g.dv, dw, g.rows, g.row0, g.n, g.lda, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol);
+            return hipGetLastError();
+        }
+    }
     hipExtLaunchKernelGGL((k_spmv_dia<MODE, CH>), dim3(pl.grid), dim3(256), 0, s, g.e0, g.e1, 0, g.dv, g.rows, g.row0, g.n,
                           g.lda, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol);
     return hipGetLastError();
@@ -1403,10 +1576,10 @@ hipError_t dispatch_dia(const GemvPlan &pl, const DiaArgs &g, hipStream_t s)
 
 }  // namespace
 
-hipError_t launch_spmv_dia_plain(const GemvPlan &pl, const DiaView &dv, int rows, int row0, int n, const double *v_full,
-                                 double *Ap, double *partials, Scalars *sc, hipStream_t s)
+hipError_t launch_spmv_dia_plain(const GemvPlan &pl, const DiaView &dv, int rows, int row0, int n, long lda,
+                                 const double *v_full, double *Ap, double *partials, Scalars *sc, hipStream_t s)
 {
-    return dispatch_dia<kPlain>(pl, DiaArgs{dv, rows, row0, n, 0L, v_full, nullptr, SegView{}, Ap, partials, sc, 0, 0.0}, s);
+    return dispatch_dia<kPlain>(pl, DiaArgs{dv, rows, row0, n, lda, v_full, nullptr, SegView{}, Ap, partials, sc, 0, 0.0}, s);
 }
 
 hipError_t launch_spmv_dia_fused(const GemvPlan &pl, const DiaView &dv, int rows, int row0, int n, long lda,

@@ -119,7 +119,7 @@ namespace cgxi {
 cgx_status run_gemv_plain(cgx_ctx *ctx, Shard &s, const double *v_full)
 {
     if (ctx->banded)
-        HIP_TRY(ctx, cgx::launch_spmv_dia_plain(s.plan, s.dia, s.rows, s.row0, ctx->n, v_full, s.Ap(), s.k1_part(), s.sc,
+        HIP_TRY(ctx, cgx::launch_spmv_dia_plain(s.plan, s.dia, s.rows, s.row0, ctx->n, ctx->lda, v_full, s.Ap(), s.k1_part(), s.sc,
                                                 ctx->stream));
     else
         HIP_TRY(ctx, cgx::launch_gemv_plain(s.plan, s.A, ctx->lda, s.rows, v_full, v_full + s.row0, s.Ap(), s.k1_part(),

@@ -126,6 +126,61 @@ def test_banded_matvec_generated(gpu_pkg, n, p):
     assert abs(pap - v @ yo) <= 1e-12 * np.sum(np.abs(v * yo))
 
 
+K1B_DIRECT, K1B_WINDOWS = 30001, 30002      # cgx_config.gemv_variant: the two forms of K1b (default: by size)
+
+
+@pytest.mark.parametrize("n,p", [(1, 1), (2, 1), (3, 1), (63, 1), (511, 1), (512, 1), (513, 1), (1000, 3), (2049, 1), (2048, 8), (5, 8),
+                                 (70001, 1), (600000, 2), (1000003, 3)])
+def test_banded_matvec_lds_windows_equal_the_direct_form_bit_for_bit(gpu_pkg, n, p):
+    """The LDS-window form of K1b fetches each window of p once per 512-row tile; the arithmetic and its order are the
+    direct form's, so Ap and p.Ap must be identical bits -- on odd sizes, odd row offsets of the shards (n=1000, P=3:
+    rows start at 333), first and last tiles, and tiles behind the block."""
+    rng = np.random.default_rng(n + p)
+    v = rng.standard_normal(n)
+    out = []
+    for variant in (K1B_DIRECT, K1B_WINDOWS):
+        with gpu_pkg.CGSolver(comm_mode=gpu_pkg.COMM_LOOPBACK if p > 1 else gpu_pkg.COMM_SELF, nranks=p,
+                              matrix_format=gpu_pkg.MATRIX_BANDED, gemv_variant=variant) as s:
+            s.generate_lap2d_matrix(n)
+            out.append(s.probe_gemv(v))
+    assert np.array_equal(out[0][0], out[1][0]) and out[0][1] == out[1][1]
+
+
+@pytest.mark.parametrize("offsets", [[0], [-1, 0, 1], [-700, -300, -299, 0, 1, 2, 300, 999], list(range(-20, 21)),
+                                     [-2500 + 600 * i for i in range(9)]])
+def test_banded_lds_windows_arbitrary_diagonals(gpu_pkg, oracle, offsets):
+    """Caller matrices with other diagonal sets: one window, several windows with gaps, 41 adjacent diagonals in one
+    window, and nine far-apart diagonals (more windows than the kernel takes: the direct form must run instead)."""
+    n = 3001
+    rng = np.random.default_rng(len(offsets))
+    A = np.zeros((n, n))
+    for o in offsets:
+        idx = np.arange(max(0, -o), min(n, n - o))
+        A[idx, idx + o] = rng.standard_normal(idx.size)
+    v = rng.standard_normal(n)
+    yo = oracle.gemv(A, v)
+    for variant in (K1B_DIRECT, K1B_WINDOWS):
+        with gpu_pkg.CGSolver(matrix_format=gpu_pkg.MATRIX_BANDED, gemv_variant=variant) as s:
+            s.set_matrix_dense(A)
+            assert s.matrix_format()[1] == sorted(offsets)
+            y, pap = s.probe_gemv(v)
+        assert np.max(np.abs(y - yo)) <= 1e-13 * np.max(np.abs(yo))
+        assert abs(pap - oracle.dot(v, yo)) <= 1e-11 * np.sum(np.abs(v * yo))
+
+
+@pytest.mark.parametrize("n,max_iter,mode,p", [(1000, 150, 1, 3), (2048, 200, None, 1), (70001, 120, None, 1), (300000, 100, 1, 2)])
+def test_banded_solve_lds_windows_equal_the_direct_form(gpu_pkg, n, max_iter, mode, p):
+    """Whole solves (fused K1b: head, p = r + beta p formed on the way into LDS, p_new stored) with both forms."""
+    res = []
+    for variant in (K1B_DIRECT, K1B_WINDOWS):
+        with make(gpu_pkg, n, mode, p, max_iter, gemv_variant=variant) as s:
+            x = np.zeros(n)
+            r = s.solve(x)
+            res.append((x, r))
+    assert np.array_equal(res[0][0], res[1][0])
+    assert res[0][1]["residual_prev"] == res[1][1]["residual_prev"] and res[0][1]["iterations"] == res[1][1]["iterations"] == max_iter
+
+
 def test_banded_matvec_equals_dense_matvec_on_the_same_matrix(gpu_pkg):
     n = 3000
     rng = np.random.default_rng(3)
