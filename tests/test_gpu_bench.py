@@ -138,3 +138,23 @@ def test_bench_auto_transport_one_rank_under_the_launcher(gpu_pkg):
     assert c["transport"] in ("p2p", "p2p-sep", "rccl") and c["transport_notes"] is None
     assert c["transport"] == min(c["transport_calibration_ms_per_iteration"], key=c["transport_calibration_ms_per_iteration"].get)
     assert d["value"] > 0 and d["roofline"]["consistency"] == "ok" and d["roofline"]["launches_timed"] == 19
+
+
+def test_bench_four_ranks_uneven_partition(gpu_pkg, oracle):
+    """Four ranks sharing the GPU (gloo control plane), N = 10001: the last rank owns one row more (cg.cc:255-266), so the
+    per-rank rows, bytes and K1 statistics differ between ranks and the roofline is taken from the rank furthest below it."""
+    n = 10001
+    r = torchrun(4, 29725, ["--steps", "24", "--warmup", "4", "--matrix-size", str(n)], env={"CGX_BENCH_BACKEND": "gloo"}, timeout=600)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    d = one_line(r.stdout)
+    c = d["config"]
+    assert d["n_gpus"] == 4 and c["ranks_seen"] == 4 and c["transport_ranks_wired"] == [4, 4, 4, 4] and c["distinct_gpus"] == 1
+    assert [q["rows"] for q in d["k1_per_rank"]] == [2500, 2500, 2500, 2501]
+    assert [q["bytes_per_launch"] for q in d["k1_per_rank"]] == [8.0 * (rows * n + n + rows) for rows in (2500, 2500, 2500, 2501)]
+    assert all(q["launches_timed"] >= 10 and q["launches_discarded"] == 1 for q in d["k1_per_rank"])     # every 2nd of 24
+    rf = d["roofline"]
+    assert rf["rank"] in (0, 1, 2, 3) and rf["bytes_per_launch"] == d["k1_per_rank"][rf["rank"]]["bytes_per_launch"]
+    assert rf["achieved"] == min(q["GBs"] for q in d["k1_per_rank"])
+    assert d["iterations_done"] == 28 and d["solve_window"]["iterations"] == 24
+    _, ro = oracle.solve_lap2d(n, 28, 0.0, 4)
+    assert abs(d["residual_after_run"] - ro["residual_prev"]) <= 1e-6 * ro["residual_prev"]

@@ -8,13 +8,15 @@ import __graft_entry__ as g
 pkg = g.load_package(); O = g.load_oracle()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
-VARIANTS = [0, 0, 0, 10821, 10811, 10441, 10421, 10241, 10281, 10181, 11611, 20821, 20441, 20241, 20181]
+VARIANTS = [0, 0, 0, 10821, 10811, 10441, 10421, 10241, 10281, 10181, 11611, 20821, 20441, 20241, 20181,
+            10822, 10842, 10442, 10282, 11612]   # ..2: the one-round form of the column-split K1
+BANDED_VARIANTS = [0, 30001, 30002]        # K1b: default / direct / LDS windows
 t0 = time.time(); cases = 0; worst = 0.0
 while time.time() - t0 < budget:
     n = int(rng.choice([rng.integers(1, 40), rng.integers(40, 700), rng.integers(700, 3000), rng.integers(3000, 6000)]))
     P = int(rng.choice([1, 1, 2, 3, 4, 5, 7, 8, 11, 16]))
     banded = bool(rng.integers(0, 2))
-    variant = 0 if banded else int(rng.choice(VARIANTS))
+    variant = int(rng.choice(BANDED_VARIANTS)) if banded else int(rng.choice(VARIANTS))
     iters = int(rng.integers(1, 40))
     iters = max(1, min(iters, n // 2))   # past ~n iterations the recurrence only moves rounding noise
     every = int(rng.choice([0, 1, 3, 16]))
