@@ -189,6 +189,8 @@ class Bench:
         self.n = problem_size(args, world)
         self.notes = []
         self.prewarm_iterations = {}
+        self.gpu_work_s = 0.0          # seconds of solver work this rank put on its GPU (pre-warm, calibration, timed run, window)
+        self.gpu_iterations = 0
 
     # ---- plumbing ------------------------------------------------------------------------------------
     def log(self, msg):
@@ -369,6 +371,8 @@ class Bench:
             ok = False
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0     # this rank's K steps are done; the MAX over ranks below is the job's time
+        self.gpu_work_s += elapsed
+        self.gpu_iterations += warmup + steps
         if dist is not None:
             dist.barrier()                     # closes the bracket; its own latency (a collective launch) is not CG work
         res, samples = None, None
@@ -573,6 +577,11 @@ class Bench:
         if window is not None:
             line["solve_window_iterations_per_s"] = window["iterations_per_s"]
             line["solve_window"] = window
+            self.gpu_work_s += window["seconds_solve"]
+            self.gpu_iterations += window["iterations"]
+        # for a reader of a GPU-utilisation sampler beside this line: how much device work the process did in all (the
+        # rest of a 1-GPU run's wall time is the CPU baseline, which keeps the GPU idle)
+        line["gpu_work"] = {"seconds_in_timed_loops": self.gpu_work_s, "cg_iterations_on_device": self.gpu_iterations}
         if world == 1 and not args.no_cpu_baseline:
             self.state["stage"] = "cpu baseline"
             line["cpu_baseline"] = cpu_baseline(n, args.cpu_baseline_iters)
