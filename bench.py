@@ -282,6 +282,12 @@ class Bench:
 
         def stage(what, fn, bounded=True):
             ok = True
+            if bounded and os.environ.get("CGX_BENCH_TEST_HANG") == "%s:%s" % (transport, what):
+                inner = fn                            # test hook (tests/test_gpu_bench.py): this stage never comes back
+
+                def fn():                             # noqa: F811
+                    time.sleep(3600)
+                    return inner()
             try:
                 ok = (call_with_timeout(fn, args.wireup_timeout, "%s/%s" % (transport, what)) if bounded else fn()) is not False
             except BaseException as e:               # noqa: BLE001 -- any failure means "do not use this transport"

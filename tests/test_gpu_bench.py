@@ -158,3 +158,16 @@ def test_bench_four_ranks_uneven_partition(gpu_pkg, oracle):
     assert d["iterations_done"] == 28 and d["solve_window"]["iterations"] == 24
     _, ro = oracle.solve_lap2d(n, 28, 0.0, 4)
     assert abs(d["residual_after_run"] - ro["residual_prev"]) <= 1e-6 * ro["residual_prev"]
+
+
+def test_bench_survives_a_wireup_stage_that_never_returns(gpu_pkg):
+    """A hung ncclCommInitRank (simulated: the stage sleeps for an hour) is abandoned after --wireup-timeout, RCCL is
+    dropped with a note, the mailbox transports carry the run, and the process still ends (os._exit past the stuck thread)."""
+    r = torchrun(1, 29726, ["--steps", "20", "--warmup", "5", "--matrix-size", "4096", "--no-cpu-baseline", "--wireup-timeout", "3"],
+                 env={"CGX_BENCH_TEST_HANG": "rccl:ncclCommInitRank"}, timeout=300)
+    d = one_line(r.stdout)
+    c = d["config"]
+    assert d["value"] > 0 and c["transport"] in ("p2p", "p2p-sep")
+    assert set(c["transport_calibration_ms_per_iteration"]) == {"p2p", "p2p-sep"}
+    assert any("rccl" in note and "did not finish within 3 s" in note for note in c["transport_notes"])
+    assert r.returncode == 0, r.stderr[-2000:]
