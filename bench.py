@@ -506,6 +506,7 @@ class Bench:
         my_rows = counts[rank]
         k1_rows = self.gather_rows([my_rows, res["gemv_launches"], res["gemv_discarded"], res["gemv_ms_min"],
                                     res["gemv_ms_median"], res["gemv_ms_avg"], res["gemv_ms_max"]])
+        dev_ms = self.max_over_ranks(res.get("steps_device_ms", 0.0))
         info = solver.comm_info()
         devices = self.gather_strings(info["device_id"])
         wired = self.gather_rows([info["ranks_wired"], info["rank_seen"]])
@@ -574,6 +575,10 @@ class Bench:
         if world > 1:
             line["k1_per_rank"] = per_rank
             line["k1_slowest_rank"] = slowest["rank"] if slowest else None
+        if dev_ms > 0:
+            # the same K steps on the device's own clock (markers in front of the first and behind the last kernel of
+            # the timed call, max over ranks): what is left to ms_per_step is launch latency and the final synchronise
+            line["device_window_ms_per_step"] = dev_ms / args.steps
         line["aggregate_gemv_GBs"] = sum(r["GBs"] for r in timed_ranks) if timed_ranks else None
         line["whole_iteration_GBs_per_gpu"] = 8.0 * (rows0 * n + n + 14 * rows0) / (elapsed / args.steps) / 1e9
         if 0 < len(samples) <= 64:

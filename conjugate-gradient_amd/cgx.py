@@ -49,7 +49,7 @@ class Result(C.Structure):
         ("seconds_solve", C.c_double), ("seconds_loop", C.c_double), ("gemv_ms_avg", C.c_double),
         ("gemv_ms_min", C.c_double), ("gemv_launches", C.c_longlong), ("gemv_bytes", C.c_double),
         ("gemv_ms_median", C.c_double), ("gemv_ms_max", C.c_double), ("gemv_discarded", C.c_longlong),
-        ("reserved", C.c_double * 1),
+        ("steps_device_ms", C.c_double),
     ]
 
     def as_dict(self):

@@ -484,6 +484,8 @@ cgx_status cgx_destroy(cgx_ctx *ctx)
         if (ctx->d_p2p_err) (void)hipFree(ctx->d_p2p_err);
     }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+    for (auto e : ctx->steps_ev)
+        if (e) (void)hipEventDestroy(e);
     for (auto e : ctx->flag_ev)
         if (e) (void)hipEventDestroy(e);
     if (ctx->h_flags) (void)hipHostFree(ctx->h_flags);

@@ -94,6 +94,9 @@ struct cgx_ctx {
     long long gemv_launches = 0, gemv_discarded = 0;
     long long gemv_seq = 0;              // K1 launches of the current cgx_solve_steps call
     std::vector<float> gemv_samples;     // their durations (ms), most recent steps call
+    hipEvent_t steps_ev[2] = {nullptr, nullptr};   // markers around the kernels of the most recent steps call (profiling on)
+    bool steps_ev_pending = false;
+    double steps_device_ms = 0;
 
     int fault_after = -1;     // >= 0: HIP_TRY calls left until one is made to fail (CGX_FAULT_AFTER, error-path tests only)
 

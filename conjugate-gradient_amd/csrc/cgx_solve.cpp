@@ -173,6 +173,8 @@ void reset_gemv_stats(cgx_ctx *ctx)
     ctx->gemv_launches = ctx->gemv_discarded = 0;
     ctx->gemv_seq = 0;
     ctx->gemv_samples.clear();
+    ctx->steps_ev_pending = false;
+    ctx->steps_device_ms = 0;
 }
 
 // Fold the recorded event pairs into the running K1 statistics (call after a stream sync).
@@ -188,6 +190,12 @@ cgx_status harvest_gemv_events(cgx_ctx *ctx)
         ctx->gemv_samples.push_back(ms);
     }
     ctx->ev_used = 0;
+    if (ctx->steps_ev_pending) {
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->steps_ev[0], ctx->steps_ev[1]));
+        ctx->steps_device_ms = ms;
+        ctx->steps_ev_pending = false;
+    }
     return CGX_OK;
 }
 
@@ -295,6 +303,11 @@ cgx_status cgx_solve_steps(cgx_ctx *ctx, int nsteps, int *done_out)
     const double t0 = wall_now();
     // K1 statistics describe the most recent steps call (bench.py: the timed region, not the warmup)
     reset_gemv_stats(ctx);
+    if (ctx->cfg.profile_gemv && nsteps > 0 && !ctx->done) {
+        for (auto &e : ctx->steps_ev)
+            if (!e) HIP_TRY(ctx, hipEventCreate(&e));
+        HIP_TRY(ctx, hipEventRecord(ctx->steps_ev[0], ctx->stream));
+    }
     const int every = ctx->cfg.check_every;
     int slot = 0;
     bool pending[2] = {false, false};
@@ -316,6 +329,10 @@ cgx_status cgx_solve_steps(cgx_ctx *ctx, int nsteps, int *done_out)
             pending[slot] = false;
             if (ctx->h_flags[2 * slot]) stop = true;   // identical on every rank: rsnew is bit-identical (cg.cc:117-121)
         }
+    }
+    if (ctx->cfg.profile_gemv && ctx->steps_ev[1] && nsteps > 0) {
+        HIP_TRY(ctx, hipEventRecord(ctx->steps_ev[1], ctx->stream));
+        ctx->steps_ev_pending = true;
     }
     CGX_TRY(read_flags_sync(ctx));
     // the event pairs are read later (cgx_get_gemv_samples / cgx_solve_end): the elapsed-time queries of a few dozen
@@ -360,7 +377,7 @@ cgx_status cgx_solve_end(cgx_ctx *ctx, double *x, cgx_result *res)
     if (x && ctx->h_stage) HIP_TRY(ctx, cgx::launch_copy_doubles(ctx->h_stage, s0.p[0], ctx->n, st));   // writes the pinned buffer
     else if (x) HIP_TRY(ctx, hipMemcpyAsync(x, s0.p[0], (size_t)ctx->n * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    if (ctx->ev_used) CGX_TRY(harvest_gemv_events(ctx));
+    if (ctx->ev_used || ctx->steps_ev_pending) CGX_TRY(harvest_gemv_events(ctx));
     if (x && x_dst != x) memcpy(x, x_dst, (size_t)ctx->n * sizeof(double));
     if (ctx->cfg.comm_mode == CGX_COMM_SELF)
         for (int v = 0; v < cgx::kSlots; ++v) hg[v] = hs.local[v];
@@ -385,6 +402,7 @@ cgx_status cgx_solve_end(cgx_ctx *ctx, double *x, cgx_result *res)
         res->gemv_ms_min = ctx->gemv_ms_min;
         res->gemv_ms_max = ctx->gemv_ms_max;
         res->gemv_discarded = ctx->gemv_discarded;
+        res->steps_device_ms = ctx->steps_device_ms;
         if (!ctx->gemv_samples.empty()) {
             std::vector<float> v(ctx->gemv_samples);
             const size_t mid = v.size() / 2;
@@ -402,7 +420,7 @@ cgx_status cgx_solve_end(cgx_ctx *ctx, double *x, cgx_result *res)
 cgx_status cgx_get_gemv_samples(cgx_ctx *ctx, double *ms_out, int cap, int *count)
 {
     if (!ctx || !count || (cap > 0 && !ms_out)) return CGX_ERR_BAD_ARG;
-    if (ctx->ev_used) {
+    if (ctx->ev_used || ctx->steps_ev_pending) {
         if (hipSetDevice(ctx->device) != hipSuccess) return CGX_ERR_HIP;
         CGX_TRY(harvest_gemv_events(ctx));
     }

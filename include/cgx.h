@@ -108,7 +108,9 @@ typedef struct cgx_result {
     double gemv_ms_median;    /* median of the samples (SURVEY.md section 8d asks for the median) */
     double gemv_ms_max;
     long long gemv_discarded; /* launches deliberately not sampled although profiling was on: the first one after a drained stream */
-    double reserved[1];
+    double steps_device_ms;   /* the most recent cgx_solve_steps call on the DEVICE's clock: from a marker in front of its first
+                                 kernel to one behind its last (0 if profiling is off); the host's wall clock around the same
+                                 call additionally holds launch latency and the final synchronisation */
 } cgx_result;
 
 typedef struct cgx_ctx cgx_ctx;

@@ -63,6 +63,7 @@ def test_bench_short_window_statistics(gpu_pkg, oracle):
     assert rf["bytes_per_launch"] == 8.0 * (n * n + n + n)
     assert "traffic_source" in rf and "NOT a counter of this run" in rf["traffic_source"]
     assert len(d["k1_samples_ms"]) == 19
+    assert rf["median_launch_ms"] < d["device_window_ms_per_step"] <= d["ms_per_step"]      # K1 < device window <= host window
     w = d["solve_window"]
     assert w["iterations"] == 20 and abs(d["solve_window_iterations_per_s"] - 20 / w["seconds_solve"]) < 1e-9 * d["value"]
     assert d["solve_window_iterations_per_s"] < d["value"]          # the window also holds set-up and two more GEMVs
