@@ -49,12 +49,6 @@ __device__ __forceinline__ double safeguarded_alpha(double rsold, double conj)
 // ------------------------------------------------------------------------------------------------
 // reductions: fixed order => bitwise reproducible for a given launch shape
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double wave_sum(double v)
-{
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;   // every lane holds the total
-}
 
 // Sums of R independent per-lane values over the 64 lanes at once (R a power of two).  Instead of R butterflies of six
 // exchanges each, the lanes first split the rows among themselves: at every halving step a lane keeps half of its rows
@@ -85,6 +79,11 @@ __device__ __forceinline__ double group_sum(double v)
     if constexpr (SPAN > 4) v = dpp_add<0x141>(v);
     if constexpr (SPAN > 8) v = dpp_add<0x140>(v);
     return v;
+}
+
+__device__ __forceinline__ double wave_sum(double v)
+{
+    return group_sum<64>(v);   // every lane holds the total
 }
 
 template <int R, int N, int WIDTH>
