@@ -55,6 +55,7 @@ void free_shard(Shard &s)
     (void)hipFree(s.apg);
     (void)hipFree(s.rbuf);
     (void)hipFree(s.partials);
+    (void)hipFree(s.ap_parts);
     (void)hipFree(s.sc);
     (void)hipFree(s.gathered);
     s = Shard{};
@@ -185,6 +186,10 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
         s.rv = cgx::SegView{s.rbuf, (int)ctx->lda + rr_parts, (int)ctx->lda, n, 1, n, 0, 0, 0, 0};
         cgx::seg_finalize(&s.rv);
         HIP_TRY(ctx, hipMalloc(&s.partials, (size_t)s.npartials * sizeof(double)));
+        if (s.plan.split > 1) {
+            HIP_TRY(ctx, hipMalloc(&s.ap_parts, (size_t)s.plan.split * ctx->seg_Sr * sizeof(double)));
+            HIP_TRY(ctx, hipMemsetAsync(s.ap_parts, 0, (size_t)s.plan.split * ctx->seg_Sr * sizeof(double), ctx->stream));
+        }
         HIP_TRY(ctx, hipMalloc(&s.sc, sizeof(Scalars)));
         HIP_TRY(ctx, hipMalloc(&s.gathered, (size_t)cgx::kMaxRanks * cgx::kSlots * sizeof(double)));
         HIP_TRY(ctx, hipMemsetAsync(s.p[0], 0, (size_t)ctx->lda * sizeof(double), ctx->stream));

@@ -28,6 +28,7 @@ struct Shard {
     double *p[2] = {nullptr, nullptr};   // lda doubles each: the replicated p (cg.cc:57), ping-pong over iterations
     double *apg = nullptr;       // nranks * S doubles: exchanged segments [Ap slice | p.Ap partials] (cgx::SegView apv)
     double *rbuf = nullptr;      // lda + kSlots doubles: the replicated r and its scalars (cgx::SegView rv, one segment)
+    double *ap_parts = nullptr;  // plan.split > 1: split x seg_Sr doubles, the column pieces of the fused K1's Ap
     double *partials = nullptr;  // scratch: per-workgroup partial sums of K3 and of the setup kernels
     Scalars *sc = nullptr;
     double *gathered = nullptr;  // kMaxRanks * kSlots doubles (DEBUG scalars of all ranks)

@@ -54,6 +54,8 @@ struct GemvPlan {
     int rows_per_wg;
     int ncols;       // columns the sweep covers: the logical n rounded up to even (16-B pieces); the pad columns up to the
                      // pitch are zero in A and in every vector and are never touched
+    int split;       // variant 1, fused launches only: column pieces per row group (1 = none).  grid counts ALL workgroups
+                     // (row groups x split) = the number of p.Ap partials; a plain launch uses grid / split
     int light;       // variant 1: the one-round form (grid <= 512 workgroups, at most two per CU; see k_gemv_colsplit)
 };
 
@@ -70,10 +72,14 @@ hipError_t launch_gemv_plain(const GemvPlan &plan, const double *A, long lda, in
 // on the fly for every column (and stored once), Ap = A p_new, partials[wg] = the workgroup's part of p_new_local . Ap.
 // e_start / e_stop (both or neither): bound to the dispatch itself (hipExtLaunchKernel), so their difference is the
 // kernel's own begin -> end as rocprofv3 sees it, with no marker packets on the stream.
+// plan.split > 1: Ap is the first of plan.split partial vectors, ap_stride doubles apart (piece s of the columns
+// writes Ap + s * ap_stride); the consumer adds them in ascending order (launch_combine_ap, or the fused P2P update).
 hipError_t launch_gemv_fused(const GemvPlan &plan, const double *A, long lda, int rows, int row0,
                              const double *p_old, double *p_new, SegView seg, double *Ap, double *partials,
                              Scalars *sc, int k, double tol, hipStream_t s, hipEvent_t e_start = nullptr,
-                             hipEvent_t e_stop = nullptr);
+                             hipEvent_t e_stop = nullptr, long ap_stride = 0);
+// dst[i] = parts[i] + parts[stride + i] + ... (split terms, ascending), i < count
+hipError_t launch_combine_ap(const double *parts, int split, long stride, int count, double *dst, hipStream_t s);
 
 // K3: p.Ap = fixed-order sum over all ranks q of the tail_count doubles at tail_off of segment q's tail;
 // alpha = rsold / max(p.Ap, rsold*1e-14); x_sub += alpha p_sub (own rows); r -= alpha Ap for ALL n rows (r is
@@ -174,9 +180,12 @@ hipError_t launch_mailbox_allgather(const MailboxView &mv, int chan, unsigned lo
 // K3 with the iteration's exchange inside (CGX_COMM_P2P): workgroups 0..P-1 push [Ap slice | folded partial] to
 // their peer, every workgroup waits (bounded) for all flags and reads the Ap element of its row and the P scalars
 // straight from the mailbox.  The iteration is then K1 + this kernel.
+// ap_parts != nullptr: this rank's Ap slice exists only as `split` partial vectors (column pieces of K1), `stride` apart;
+// pushers and own rows add them up in ascending order on the fly.
 hipError_t launch_update_xr_p2p(int n, int rows, int row0, const double *p_new, SegView apv, int npart,
                                 const MailboxView &mv, int chan, unsigned long long epoch, double *x, SegView rv, Scalars *sc,
-                                int parity, long long timeout_ticks, int *err, hipStream_t s);
+                                int parity, long long timeout_ticks, int *err, hipStream_t s,
+                                const double *ap_parts = nullptr, int split = 1, long stride = 0);
 
 // Loopback "collective": copy local[kSlots] of every shard into gathered[] of every shard (<= 16 shards).
 hipError_t launch_loopback_gather(double *const *gathered_ptrs, const Scalars *const *scalar_ptrs, int nshards,

@@ -277,11 +277,11 @@ __device__ __forceinline__ d2 make_p(const SegView &sv, double beta, d2 p_old, i
 // measured in round 2: no faster -- 157.0 us against 157.2 on the 4096 x 32768 shard -- and dropped again; what limits
 // this shape is the access pattern itself, tools/hbm_rows_bw.hip.)
 template <int R, int U, int WAVES, int MODE, bool LIGHT = false>
-__global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 1))) void k_gemv_colsplit(const double *__restrict__ A, long lda, int ncols, int rows,
+__global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 1))) void k_gemv_colsplit(const double *__restrict__ A, long lda, int ncols_all, int rows,
                                                                int row0_global, const double *__restrict__ v,
                                                                double *__restrict__ p_new, SegView sv,
                                                                double *__restrict__ Ap, double *partials,
-                                                               Scalars *sc, int k, double tol)
+                                                               Scalars *sc, int k, double tol, int split, long ap_stride)
 {
     constexpr bool FUSED = MODE != kPlain;
     constexpr bool NT = true;   // A is streamed once: non-temporal loads keep p and r in L2 (+12 % measured)
@@ -289,7 +289,26 @@ __global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 
 
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
-    const long row0 = (long)blockIdx.x * R;
+    // split > 1 (shards of a multi-GPU run): the columns of a row group are cut into `split` pieces of whole trips, one
+    // workgroup each, piece-major (blockIdx = piece * groups + group).  split times as many, shorter workgroups give the
+    // launch several rounds, so that prologue and epilogue of one workgroup hide behind the sweep of the others, as they
+    // do in the 4096-workgroup launch of the whole matrix.  Piece s writes its partial row sums to Ap + s * ap_stride;
+    // whoever consumes Ap adds the pieces in ascending order.  The p.Ap partial is linear in Ap and needs no combine.
+    const int groups = (int)gridDim.x / split;
+    const int piece = (int)blockIdx.x / groups;
+    const long row0 = (long)((int)blockIdx.x - piece * groups) * R;
+    int ncols = ncols_all;
+    int c_first = 0;
+    if (split > 1) {
+        constexpr int kTrip = U * WAVES * 128;
+        const int trips = (ncols_all + kTrip - 1) / kTrip;
+        const int per = (trips + split - 1) / split;
+        c_first = piece * per * kTrip;
+        const long hi = (long)(piece + 1) * per * kTrip;
+        ncols = hi < ncols_all ? (int)hi : ncols_all;
+        if (c_first > ncols) c_first = ncols;
+        Ap += (long)piece * ap_stride;
+    }
     // ncols = n rounded up to even: the pad columns up to the pitch hold zeros in A and in the vectors and are skipped
     // (sweeping them cost wave 0 of every workgroup one more, fully exposed, memory round trip at the end of its rows)
     const double *rfull = sv.base;   // FUSED: the replicated r, contiguous and zero padded up to lda
@@ -309,9 +328,12 @@ __global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 
     for (int r = 0; r < R; ++r) { acc0[r] = 0.0; acc1[r] = 0.0; }
 
     constexpr int kStep = WAVES * 128;   // doubles swept by the workgroup per step
-    int c = w * 128 + lane * 2;
-    int step = 0;                        // index of the step this trip starts with
-    int my_step = (int)blockIdx.x;       // next step whose p_new this workgroup stores
+    int c = c_first + w * 128 + lane * 2;
+    int step = c_first / kStep;          // index of the step this trip starts with
+    // next step whose p_new this workgroup stores: step st belongs to the row group st mod groups (of the piece that
+    // sweeps it), so every step is stored exactly once
+    int my_step = (int)blockIdx.x - piece * groups;
+    if (my_step < step) my_step += ((step - my_step + groups - 1) / groups) * groups;
     double beta = 0.0;
     double ep_v = 0.0, ep_r = 0.0;       // LIGHT: the epilogue's operands, fetched ahead of the sweep
 
@@ -338,7 +360,7 @@ __global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 
                 pvx[u].y = fma(beta, pvx[u].y, rvx[u].y);
                 if (st + u == my_step) {
                     *reinterpret_cast<d2 *>(reinterpret_cast<char *>(p_new) + (unsigned)(cc + u * kStep) * 8u) = pvx[u];
-                    my_step += (int)gridDim.x;
+                    my_step += groups;
                 }
             }
 #pragma unroll
@@ -401,7 +423,7 @@ __global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 
             p1.y = fma(beta, p1.y, r1.y);
             if (step == my_step) {
                 *reinterpret_cast<d2 *>(p_new + c) = p1;
-                my_step += (int)gridDim.x;
+                my_step += groups;
             }
         }
 #pragma unroll
@@ -585,6 +607,21 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_ldsp(const double *__restri
         for (int i = 1; i < WAVES; ++i) tot += red[i];
         partials[blockIdx.x] = tot;
     }
+}
+
+// The column pieces of a split K1 added up into the Ap slice (every consumer but the fused P2P update, which does it itself).
+__global__ __launch_bounds__(256) void k_combine_ap(const double *__restrict__ parts, int split, long stride, int count,
+                                                     double *__restrict__ dst)
+{
+    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 2;
+    if (i >= count) return;
+    d2 a = *reinterpret_cast<const d2 *>(parts + i);            // count is padded to even, slices are 16-B aligned
+    for (int sp = 1; sp < split; ++sp) {
+        const d2 b = *reinterpret_cast<const d2 *>(parts + sp * stride + i);
+        a.x += b.x;
+        a.y += b.y;
+    }
+    *reinterpret_cast<d2 *>(dst + i) = a;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1201,7 +1238,8 @@ __global__ __launch_bounds__(256) void k_mailbox_allgather(MailboxView mv, int c
 __global__ __launch_bounds__(256) void k_update_xr_p2p(int n, int rows, int row0, const double *__restrict__ p_new,
                                                         SegView apv, int npart, MailboxView mv, int chan,
                                                         unsigned long long epoch, double *__restrict__ x, SegView rv,
-                                                        Scalars *sc, int parity_rs, long long timeout_ticks, int *err)
+                                                        Scalars *sc, int parity_rs, long long timeout_ticks, int *err,
+                                                        const double *__restrict__ ap_parts, int split, long part_stride)
 {
     __shared__ double lds[4];
     __shared__ double s_sums[kMaxRanks];
@@ -1237,6 +1275,17 @@ __global__ __launch_bounds__(256) void k_update_xr_p2p(int n, int rows, int row0
         if (peer == me) continue;
         double *out = reinterpret_cast<double *>(mv.base[peer] + mv.data_off[chan] + ((long)par * P + me) * slot);
         const int pairs = apv.Sr >> 1;   // Sr is even
+        if (split > 1) {
+            for (int t = tid; t < pairs; t += 256) {   // K1 left the slice as `split` column pieces: add them, ascending
+                d2 a = *reinterpret_cast<const d2 *>(ap_parts + 2 * t);
+                for (int sp = 1; sp < split; ++sp) {
+                    const d2 b = *reinterpret_cast<const d2 *>(ap_parts + sp * part_stride + 2 * t);
+                    a.x += b.x;
+                    a.y += b.y;
+                }
+                *reinterpret_cast<d2 *>(out + 2 * t) = a;
+            }
+        } else
         for (int t = tid; t < pairs; t += 256)
             *reinterpret_cast<d2 *>(out + 2 * t) = *reinterpret_cast<const d2 *>(mine + 2 * t);
         if (tid == 0) out[apv.Sr] = my_sum;
@@ -1281,7 +1330,16 @@ __global__ __launch_bounds__(256) void k_update_xr_p2p(int n, int rows, int row0
     if (in) {
         const int q = (P > 1) ? seg_owner(apv, i) : 0;
         const int off = i - q * apv.n_loc;
-        ap_i = (q == me) ? mine[off]
+        double own_ap = 0.0;
+        if (q == me) {
+            if (split > 1) {
+                own_ap = ap_parts[off];
+                for (int sp = 1; sp < split; ++sp) own_ap += ap_parts[sp * part_stride + off];   // same order as the pushers
+            } else {
+                own_ap = mine[off];
+            }
+        }
+        ap_i = (q == me) ? own_ap
                          : __longlong_as_double((long long)__hip_atomic_load(box + ((long)par * P + q) * slot_w + off,
                                                                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
     }
@@ -1327,6 +1385,7 @@ void seg_finalize(SegView *sv)
 GemvPlan plan_gemv(int variant, int rows, int n, long lda)
 {
     GemvPlan pl{};
+    pl.split = 1;
     const int ncols = (int)lda;
     pl.ncols = (n + 1) & ~1;
     if (pl.ncols > ncols) pl.ncols = ncols;
@@ -1358,7 +1417,9 @@ GemvPlan plan_gemv(int variant, int rows, int n, long lda)
         pl.R = (variant / 100) % 100;
         pl.U = (variant / 10) % 10;
         pl.nt = 1;
-        pl.light = (variant % 10) == 2;   // last digit 2: the one-round form (two workgroups per CU at most)
+        const int d = variant % 10;       // 2: the one-round form; 3 / 4 / 5: the same with the columns split 2 / 4 / 8 ways
+        pl.light = d >= 2 && d <= 5;
+        pl.split = d == 3 ? 2 : (d == 4 ? 4 : (d == 5 ? 8 : 1));
     }
     if (pl.variant == 2) {
         pl.rows_per_wg = pl.R * pl.waves;
@@ -1368,6 +1429,8 @@ GemvPlan plan_gemv(int variant, int rows, int n, long lda)
     }
     pl.grid = ceil_div(rows, pl.rows_per_wg);
     if (pl.grid < 1) pl.grid = 1;   // a shard without rows still runs the iteration head and stores p
+    if (pl.split < 1 || pl.variant != 1 || !pl.light) pl.split = 1;
+    pl.grid *= pl.split;
     if (pl.variant != 1) pl.light = 0;   // (an explicit one-round shape is honoured at any grid: it is correct, just not one round)
     return pl;
 }
@@ -1386,25 +1449,27 @@ struct GemvArgs {
     int k;
     double tol;
     hipEvent_t e0 = nullptr, e1 = nullptr;   // optional: bound to the dispatch (kernel begin / end)
+    int split = 1;                           // one-round form only: column pieces per row group
+    long ap_stride = 0;
 };
 
 template <int R, int U, int MODE>
 hipError_t launch_shape(const GemvPlan &pl, const GemvArgs &g, hipStream_t s)
 {
     if (pl.variant == 2)
-        hipExtLaunchKernelGGL((k_gemv_ldsp<R, U, 4, MODE>), dim3(pl.grid), dim3(256), 0, s, g.e0, g.e1, 0, g.A, g.lda, g.rows,
+        hipExtLaunchKernelGGL((k_gemv_ldsp<R, U, 4, MODE>), dim3(pl.grid / pl.split), dim3(256), 0, s, g.e0, g.e1, 0, g.A, g.lda, g.rows,
                               g.row0, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol);
     else
-        hipExtLaunchKernelGGL((k_gemv_colsplit<R, U, 4, MODE>), dim3(pl.grid), dim3(256), 0, s, g.e0, g.e1, 0, g.A, g.lda,
-                              pl.ncols, g.rows, g.row0, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol);
+        hipExtLaunchKernelGGL((k_gemv_colsplit<R, U, 4, MODE>), dim3(pl.grid / pl.split), dim3(256), 0, s, g.e0, g.e1, 0, g.A, g.lda,
+                              pl.ncols, g.rows, g.row0, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol, 1, 0L);
     return hipGetLastError();
 }
 
 template <int R, int U, int MODE>
 hipError_t launch_light(const GemvPlan &pl, const GemvArgs &g, hipStream_t s)
 {
-    hipExtLaunchKernelGGL((k_gemv_colsplit<R, U, 4, MODE, true>), dim3(pl.grid), dim3(256), 0, s, g.e0, g.e1, 0, g.A, g.lda,
-                          pl.ncols, g.rows, g.row0, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol);
+    hipExtLaunchKernelGGL((k_gemv_colsplit<R, U, 4, MODE, true>), dim3(pl.grid / pl.split * g.split), dim3(256), 0, s, g.e0, g.e1, 0, g.A, g.lda,
+                          pl.ncols, g.rows, g.row0, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol, g.split, g.ap_stride);
     return hipGetLastError();
 }
 
@@ -1444,9 +1509,12 @@ hipError_t launch_gemv_plain(const GemvPlan &pl, const double *A, long lda, int 
 
 hipError_t launch_gemv_fused(const GemvPlan &pl, const double *A, long lda, int rows, int row0, const double *p_old,
                              double *p_new, SegView seg, double *Ap, double *partials, Scalars *sc, int k, double tol,
-                             hipStream_t s, hipEvent_t e_start, hipEvent_t e_stop)
+                             hipStream_t s, hipEvent_t e_start, hipEvent_t e_stop, long ap_stride)
 {
     GemvArgs g{A, lda, rows, row0, p_old, p_new, seg, Ap, partials, sc, k, tol, e_start, e_stop};
+    g.split = pl.split;
+    g.ap_stride = ap_stride;
+    if (pl.split > 1 && (!pl.light || ap_stride <= 0)) return hipErrorInvalidValue;
     return dispatch_gemv<kFusedSingle>(pl, g, s);
 }
 
@@ -1472,6 +1540,7 @@ GemvPlan plan_dia(int rows, int variant)
 {
     GemvPlan pl{};
     pl.variant = 3;
+    pl.split = 1;
     pl.R = 1;
     pl.U = 1;
     pl.waves = 4;
@@ -1632,10 +1701,18 @@ hipError_t launch_dia_pack(const double *A, long lda, int n, int row0, int rows,
 
 hipError_t launch_update_xr_p2p(int n, int rows, int row0, const double *p_new, SegView apv, int npart,
                                 const MailboxView &mv, int chan, unsigned long long epoch, double *x, SegView rv, Scalars *sc,
-                                int parity, long long timeout_ticks, int *err, hipStream_t s)
+                                int parity, long long timeout_ticks, int *err, hipStream_t s, const double *ap_parts, int split,
+                                long stride)
 {
     hipLaunchKernelGGL(k_update_xr_p2p, dim3(update_xr_grid(n)), dim3(256), 0, s, n, rows, row0, p_new, apv, npart, mv, chan,
-                       epoch, x, rv, sc, parity, timeout_ticks, err);
+                       epoch, x, rv, sc, parity, timeout_ticks, err, ap_parts, ap_parts ? split : 1, stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_combine_ap(const double *parts, int split, long stride, int count, double *dst, hipStream_t s)
+{
+    if (count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(k_combine_ap, dim3(ceil_div(count, 512)), dim3(256), 0, s, parts, split, stride, count, dst);
     return hipGetLastError();
 }
 

@@ -27,7 +27,7 @@ cgx_status cgx_probe_gemv(cgx_ctx *ctx, const double *p, double *y, double *pAp)
         HIP_TRY(ctx, hipMemsetAsync(s.sc, 0, sizeof(Scalars), st));
         HIP_TRY(ctx, hipMemcpyAsync(s.p[0], p, (size_t)ctx->n * sizeof(double), hipMemcpyHostToDevice, st));
         CGX_TRY(run_gemv_plain(ctx, s, s.p[0]));
-        HIP_TRY(ctx, cgx::launch_reduce_partials(s.k1_part(), s.plan.grid, &s.sc->local[cgx::kSlotConj], st));
+        HIP_TRY(ctx, cgx::launch_reduce_partials(s.k1_part(), s.plan.grid / std::max(s.plan.split, 1), &s.sc->local[cgx::kSlotConj], st));
         double part = 0.0;
         if (s.rows > 0)
             HIP_TRY(ctx, hipMemcpyAsync(y + s.row0, s.Ap(), (size_t)s.rows * sizeof(double), hipMemcpyDeviceToHost, st));
@@ -119,6 +119,10 @@ cgx_status cgx_probe_vector_ops(cgx_ctx *ctx, int n, double alpha, double beta, 
     HIP_TRY(ctx, hipMemsetAsync(drb + lda, 0, (size_t)grid * sizeof(double), st));
     HIP_TRY(ctx, hipMemcpyAsync(drb + lda, &beta, sizeof(double), hipMemcpyHostToDevice, st));
     cgx::GemvPlan plan = cgx::plan_gemv(ctx->cfg.gemv_variant, 1, n, lda);
+    if (plan.split > 1) {   // the probe has one Ap row: no column pieces
+        plan.grid /= plan.split;
+        plan.split = 1;
+    }
     HIP_TRY(ctx, cgx::launch_gemv_fused(plan, dA, lda, 1, 0, dp0, dp1, rv, dAp1, dAp1 + 8, dsc, 1, -1.0 /* never converges */, st));
     HIP_TRY(ctx, hipMemcpyAsync(p, dp1, bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));

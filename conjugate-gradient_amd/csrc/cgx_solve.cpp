@@ -161,7 +161,8 @@ cgx_status run_gemv_fused(cgx_ctx *ctx, Shard &s, int k)
                                                 s.rv, s.Ap(), s.k1_part(), s.sc, k, ctx->tol, ctx->stream, e0, e1));
     else
         HIP_TRY(ctx, cgx::launch_gemv_fused(s.plan, s.A, ctx->lda, s.rows, s.row0, s.p[k & 1], s.p[(k + 1) & 1], s.rv,
-                                            s.Ap(), s.k1_part(), s.sc, k, ctx->tol, ctx->stream, e0, e1));
+                                            s.plan.split > 1 ? s.ap_parts : s.Ap(), s.k1_part(), s.sc, k, ctx->tol, ctx->stream,
+                                            e0, e1, ctx->seg_Sr));
     if (m1) HIP_TRY(ctx, hipEventRecord(m1, ctx->stream));
     return CGX_OK;
 }
@@ -211,9 +212,14 @@ cgx_status enqueue_iteration(cgx_ctx *ctx, int k)
         if (!ctx->p2p_ready) return fail(ctx, CGX_ERR_P2P, "cgx_p2p_import has not been called");
         const unsigned long long epoch = ++ctx->p2p_epoch[1];
         HIP_TRY(ctx, cgx::launch_update_xr_p2p(ctx->n, s.rows, s.row0, s.p[(k + 1) & 1], s.apv, ctx->npart, ctx->mv, 1, epoch,
-                                               s.x, s.rv, s.sc, k & 1, ctx->p2p_timeout_ticks, ctx->d_p2p_err, st));
+                                               s.x, s.rv, s.sc, k & 1, ctx->p2p_timeout_ticks, ctx->d_p2p_err, st,
+                                               s.plan.split > 1 ? s.ap_parts : nullptr, s.plan.split, ctx->seg_Sr));
         return CGX_OK;
     }
+    // every other consumer wants the Ap slice whole: add up the column pieces of a split K1 first
+    for (auto &s : ctx->shards)
+        if (s.plan.split > 1 && !ctx->banded)
+            HIP_TRY(ctx, cgx::launch_combine_ap(s.ap_parts, s.plan.split, ctx->seg_Sr, ctx->seg_Sr, s.Ap(), st));
     CGX_TRY(gather_segments(ctx, true));                                                             // cg.cc:106
     const bool folded = ctx->cfg.comm_mode == CGX_COMM_P2P;   // the exchange kernel already folded each rank's partials
     for (auto &s : ctx->shards)

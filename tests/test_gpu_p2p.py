@@ -30,6 +30,22 @@ def run(world, n, max_iter, tmp_path, port, variant=0, separate=0):
 ])
 def test_p2p_processes_on_one_gpu(tmp_path, world, n, max_iter, port, separate):
     v = run(world, n, max_iter, tmp_path, port, separate=separate)
+    _check_p2p(v, n)
+
+
+@pytest.mark.parametrize("world,n,max_iter,port,separate,variant", [
+    (2, 2048, 200, 29711, 0, 10444), (3, 1000, 150, 29712, 0, 10823), (4, 4096, 100, 29713, 0, 10445),   # pushers and own rows add the pieces
+    (3, 1000, 150, 29714, 1, 10444),                                                                  # separate exchange: combine kernel
+    (3, 9, 3, 29715, 0, 10444),
+])
+def test_p2p_processes_with_a_column_split_k1(tmp_path, world, n, max_iter, port, separate, variant):
+    """K1 with the columns of a row group split over several workgroups: the rank's Ap slice exists only as partial
+    vectors, which the fused update adds up on the fly (pushers and own rows, same order) -- real processes over IPC."""
+    v = run(world, n, max_iter, tmp_path, port, variant=variant, separate=separate)
+    _check_p2p(v, n)
+
+
+def _check_p2p(v, n):
     assert v["selftest_ok"], v
     assert v["ranks_agree"], v
     assert v["k"] == v["k_oracle"] or (v["converged"] and abs(v["k"] - v["k_oracle"]) <= 0.15 * v["k_oracle"]), v

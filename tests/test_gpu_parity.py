@@ -54,7 +54,8 @@ def test_generator_bit_exact(gpu_pkg, oracle, n, mode, p):
 
 # ---- K1 ------------------------------------------------------------------------------------------------
 VARIANTS = [0, 10821, 10820, 10811, 10441, 10421, 10241, 10281, 10181, 11611, 20821, 20811, 20441, 20421, 20241, 20281, 20181,
-            10822, 10842, 10442, 10282, 11612]   # last digit 2: the one-round form of the column-split kernel (shards of an 8-GPU run)
+            10822, 10842, 10442, 10282, 11612,
+            10823, 10444, 10445, 10824]   # ..3/4/5: one-round form with the columns of a row group split over 2/4/8 workgroups   # last digit 2: the one-round form of the column-split kernel (shards of an 8-GPU run)
 
 
 @pytest.mark.parametrize("variant", VARIANTS)
@@ -70,7 +71,7 @@ def test_gemv_generated(gpu_pkg, oracle, n, variant):
     assert abs(pap - oracle.dot(p, yo)) <= 1e-12 * np.sum(np.abs(p * yo))
 
 
-@pytest.mark.parametrize("variant", [10822, 10842, 10442, 10282, 11612])
+@pytest.mark.parametrize("variant", [10822, 10842, 10442, 10282, 11612, 10823, 10444, 10445])
 @pytest.mark.parametrize("n", [1023, 2047, 3000, 5200])
 def test_gemv_one_round_form_trip_counts(gpu_pkg, oracle, n, variant):
     """The one-round form (first trip issued ahead of the iteration head) on dense random A, sizes with and without a
@@ -219,6 +220,7 @@ def test_alpha_safeguard_keeps_a_nan_like_std_max(gpu_pkg, oracle):
     (2048, 200, 1, 2, 0), (2048, 200, 1, 4, 0), (2048, 200, 1, 8, 10821), (1000, 150, 1, 3, 0), (1000, 150, 1, 7, 20441),
     (4096, 50, None, 1, 0), (4096, 200, 1, 8, 0),
     (2048, 200, 1, 8, 10822), (1000, 150, 1, 3, 10842), (4096, 50, None, 1, 10822), (1024, 100, None, 1, 10282), (3000, 60, 1, 2, 11612),
+    (2048, 200, 1, 8, 10444), (1000, 150, 1, 3, 10823), (4096, 50, None, 1, 10445), (3000, 60, 1, 2, 10824), (9, 3, 1, 4, 10444),
 ])
 def test_fixed_iteration_solve_matches_oracle(gpu_pkg, oracle, n, max_iter, mode, p, variant):
     with make(gpu_pkg, n, mode, p, variant, max_iter) as s:
@@ -539,7 +541,7 @@ def test_config2_n10000_converges_like_reference(gpu_pkg, reference_probe):
 
 
 @pytest.mark.parametrize("mode,p,variant", [(None, 1, 0), (1, 2, 0), (1, 4, 0), (1, 8, 0), (None, 1, 20441), (1, 8, 20241),
-                                            (1, 8, 10822), (1, 8, 10442)])
+                                            (1, 8, 10822), (1, 8, 10442), (1, 8, 10444), (1, 4, 10824)])
 def test_config3_n32768_500_iterations(gpu_pkg, reference_probe, mode, p, variant):
     """The roofline point and (as 2/4/8 logical row blocks on one GPU) the strong-scaling partitions, with the default
     K1 and with the LDS-staged variant."""
