@@ -291,13 +291,15 @@ class Bench:
             try:
                 ok = (call_with_timeout(fn, args.wireup_timeout, "%s/%s" % (transport, what)) if bounded else fn()) is not False
             except BaseException as e:               # noqa: BLE001 -- any failure means "do not use this transport"
+                if isinstance(e, TimeoutError):
+                    box["stuck"] = True              # a helper thread may still be inside the library with this context
                 self.log("transport %s unavailable (%s): %s" % (transport, what, e))
                 self.notes.append("%s dropped at '%s' on rank %d: %s" % (transport, what, rank, str(e)[:200]))
                 ok = False
             return self.all_ok(ok)
 
         def give_up():
-            if box["s"] is not None:
+            if box["s"] is not None and not box.get("stuck"):   # never destroy a context another thread may be using
                 try:
                     box["s"].close()
                 except Exception:                    # noqa: BLE001
