@@ -76,6 +76,13 @@ int main(int argc, char **argv)
         else if (a == "--banded") banded = true;
         else if (a == "--transport" && i + 1 < argc) transport = argv[++i];
         else if (a == "--same-device") same_device = true;   // rehearsal: every rank on device 0 (p2p only)
+        else if (a == "--cpu") {
+            // SURVEY.md section 8(b) named a --cpu switch for the CPU restatement.  The product has no CPU path by design
+            // (a silent fallback would void every parity claim); the restatement is test infrastructure under oracle/.
+            std::cerr << argv[0] << ": --cpu is not available: libcgx has no CPU fallback (the CPU restatement of the\n"
+                         "reference is the parity oracle under oracle/, used by tests/ and by bench.py's cpu_baseline only)\n";
+            return 1;
+        }
         else pos.push_back(a);
     }
     if (pos.empty()) return usage(argv[0]);   // cg_main.cc:22-26 (returns 1)

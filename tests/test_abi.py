@@ -76,6 +76,8 @@ def test_cli_usage_and_failure_exit_codes(pkg):
     assert os.path.exists(exe), "cgsolver not built (run __graft_entry__.build())"
     r = subprocess.run([exe], capture_output=True, text=True)
     assert r.returncode == 1 and "Usage" in r.stderr          # code/MPI/cg_main.cc:22-26
+    r = subprocess.run([exe, "64", "/tmp/cgx_never_written.txt", "--cpu"], capture_output=True, text=True)
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr and not os.path.exists("/tmp/cgx_never_written.txt")
     if not _has_gpu():
         r = subprocess.run([exe, "64", "/tmp/cgx_never_written.txt"], capture_output=True, text=True)
         assert r.returncode == 1 and "no CPU fallback" in r.stderr
