@@ -661,3 +661,37 @@ def test_error_paths_release_device_memory(gpu_pkg):
         again = s.probe_vector_ops(0.5, 0.25, *v)
         assert all(np.array_equal(a, b) for a, b in zip(good[:3], again[:3])) and good[3] == again[3]
         assert s.p2p_selftest(2)
+
+
+# ---- size-independent properties at the BASELINE sizes -------------------------------------------------------------
+@pytest.mark.parametrize("n,mode,p", [(32768, None, 1), (32768, 1, 8), (46340, 1, 8)])
+def test_full_size_properties(gpu_pkg, oracle, n, mode, p):
+    """No CPU block can check an 8-17 GB GEMV element by element in seconds; the domain's own invariants can:
+    exact row sums of the generator's matrix (cg.cc:181-185), linearity and symmetry of the mat-vec, and the solve's
+    reported ||Ax-b||/||b|| against a fresh mat-vec of the returned x with the oracle's b."""
+    rng = np.random.default_rng(n + p)
+    inc = int(np.floor(np.sqrt(n)))
+    u, v = rng.standard_normal(n), rng.standard_normal(n)
+    a, c = 0.75, -1.5
+    with make(gpu_pkg, n, mode, p, max_iter=40) as s:
+        ones, _ = s.probe_gemv(np.ones(n))
+        expect = np.zeros(n)                       # 4 - (#neighbours present): interior rows sum to 0
+        expect[0] = expect[n - 1] = 2.0            # one +-1 and one far neighbour missing at each end
+        expect[1:inc + 1] = 1.0                    # rows 1..inc: no i-1-inc neighbour (cg.cc:184 needs i > inc)
+        expect[n - 1 - inc:n - 1] = 1.0            # rows n-1-inc..n-2: no i+1+inc neighbour (cg.cc:185)
+        assert np.array_equal(ones, expect)
+        Au, _ = s.probe_gemv(u)
+        Av, pav = s.probe_gemv(v)
+        Aw, _ = s.probe_gemv(a * u + c * v)
+        scale = 8.0 * (np.abs(a * u) + np.abs(c * v)).max()
+        assert np.max(np.abs(Aw - (a * Au + c * Av))) <= 8e-16 * scale * 6                       # linearity
+        assert abs(u @ Av - v @ Au) <= 1e-12 * (np.abs(u) @ np.abs(Av))                           # symmetry of the generated A
+        assert abs(pav - v @ Av) <= 1e-12 * (np.abs(v) @ np.abs(Av))                              # the fused p.Ap
+        assert v @ Av > 0                                                                         # positive definite
+        x = np.zeros(n)
+        r = s.solve(x)
+        Ax, _ = s.probe_gemv(x)
+    b = oracle.init_source_term(n)
+    rel_res = np.linalg.norm(Ax - b) / np.linalg.norm(b)
+    assert r["iterations"] == 40 and rel(r["rel_residual"], rel_res) < 1e-9
+    assert rel(r["x_norm"], np.linalg.norm(x)) < 1e-13
