@@ -695,3 +695,21 @@ def test_full_size_properties(gpu_pkg, oracle, n, mode, p):
     rel_res = np.linalg.norm(Ax - b) / np.linalg.norm(b)
     assert r["iterations"] == 40 and rel(r["rel_residual"], rel_res) < 1e-9
     assert rel(r["x_norm"], np.linalg.norm(x)) < 1e-13
+
+
+@pytest.mark.parametrize("n,mode,p,fmt", [(32768, None, 1, 0), (32768, 1, 8, 0), (23170, 1, 2, 0), (1 << 20, None, 1, 1)])
+def test_runs_are_bitwise_reproducible(gpu_pkg, n, mode, p, fmt):
+    """No floating-point atomics anywhere and every reduction in a fixed order: two solves of the same problem, on the
+    same context and on a fresh one, return identical bits (dense on 1, 2 and 8 row blocks; banded storage)."""
+    xs = []
+    for fresh in range(2):
+        with gpu_pkg.CGSolver(comm_mode=gpu_pkg.COMM_SELF if mode is None else mode, nranks=p, matrix_format=fmt) as s:
+            s.generate_lap2d_matrix(n)
+            s.set_max_iter(60)
+            s.init_source_term(1.0 / n)
+            for rep in range(2 - fresh):
+                x = np.zeros(n)
+                r = s.solve(x)
+                xs.append((x, r["residual_prev"], r["x_norm"], r["rel_residual"]))
+    for x, res, xn, rr in xs[1:]:
+        assert np.array_equal(x, xs[0][0]) and (res, xn, rr) == xs[0][1:]
