@@ -134,7 +134,11 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
         const char *e = getenv("CGX_GEMV_VARIANT");
         if (e) variant = atoi(e);
     }
-    auto plan_for = [&](int rows) { return ctx->banded ? cgx::plan_dia(rows, variant) : cgx::plan_gemv(variant, rows, ctx->n, ctx->lda); };
+    // the fused P2P update adds the column pieces of a split K1 on the fly; every other consumer would need a combine kernel
+    const bool allow_split = ctx->cfg.comm_mode == CGX_COMM_P2P && !ctx->cfg.p2p_separate_exchange && ctx->nranks > 1;
+    auto plan_for = [&](int rows) {
+        return ctx->banded ? cgx::plan_dia(rows, variant) : cgx::plan_gemv(variant, rows, ctx->n, ctx->lda, allow_split);
+    };
     ctx->npart = 1;
     for (int q = 0; q < ctx->nranks; ++q) ctx->npart = std::max(ctx->npart, plan_for(ctx->num_rows[q]).grid);
     if (ctx->cfg.comm_mode == CGX_COMM_P2P && n > 256 * cgx::kMaxVectorGrid)

@@ -59,8 +59,9 @@ struct GemvPlan {
     int light;       // variant 1: the one-round form (grid <= 512 workgroups, at most two per CU; see k_gemv_colsplit)
 };
 
-// Choose the K1 shape for a shard of `rows` x `n` held at pitch `lda` (variant 0 = default).
-GemvPlan plan_gemv(int variant, int rows, int n, long lda);
+// Choose the K1 shape for a shard of `rows` x `n` held at pitch `lda` (variant 0 = default).  allow_split: the consumer of
+// Ap can add column pieces itself (the fused P2P update), so the default may cut the columns of a row group into pieces.
+GemvPlan plan_gemv(int variant, int rows, int n, long lda, bool allow_split = false);
 
 // K1, plain form: Ap = A[rows x lda] * v ; partials[wg] = sum over the workgroup's rows of v_local[i]*Ap[i].
 // Used for the initial residual (cg.cc:79-81), the DEBUG verification (cg.cc:146-147) and the probes.

@@ -290,13 +290,18 @@ __global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 
     const int lane = threadIdx.x & 63;
     const int w = threadIdx.x >> 6;
     // split > 1 (shards of a multi-GPU run): the columns of a row group are cut into `split` pieces of whole trips, one
-    // workgroup each, piece-major (blockIdx = piece * groups + group).  split times as many, shorter workgroups give the
-    // launch several rounds, so that prologue and epilogue of one workgroup hide behind the sweep of the others, as they
-    // do in the 4096-workgroup launch of the whole matrix.  Piece s writes its partial row sums to Ap + s * ap_stride;
-    // whoever consumes Ap adds the pieces in ascending order.  The p.Ap partial is linear in Ap and needs no combine.
+    // workgroup each, with piece = blockIdx % split.  Workgroups are dealt round-robin over the 8 XCDs (blocks b and b+8
+    // share one), so with split = 8 every workgroup of an XCD sweeps the SAME eighth of the columns: each XCD's L2 holds
+    // and re-fetches per launch one eighth of p and r instead of all of both, and what the workgroups of an XCD wait for
+    // in lock step is that much less.  Measured on the shards of N = 32768: 154.5 -> 152.0 us (P=8, split 8),
+    // 305.4 -> 302.2 (P=4, split 4), 603.1 -> 600.2 (P=2, split 2); with piece = blockIdx / groups (pieces not tied to
+    // XCDs) the same split was 1-2 us SLOWER than no split -- the placement is what pays, not the granularity.
+    // Piece s writes its partial row sums to Ap + s * ap_stride; whoever consumes Ap adds the pieces in ascending order.
+    // The p.Ap partial is linear in Ap and needs no combine.
     const int groups = (int)gridDim.x / split;
-    const int piece = (int)blockIdx.x / groups;
-    const long row0 = (long)((int)blockIdx.x - piece * groups) * R;
+    const int piece = (int)blockIdx.x % split;
+    const int group = (int)blockIdx.x / split;
+    const long row0 = (long)group * R;
     int ncols = ncols_all;
     int c_first = 0;
     if (split > 1) {
@@ -332,7 +337,7 @@ __global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 
     int step = c_first / kStep;          // index of the step this trip starts with
     // next step whose p_new this workgroup stores: step st belongs to the row group st mod groups (of the piece that
     // sweeps it), so every step is stored exactly once
-    int my_step = (int)blockIdx.x - piece * groups;
+    int my_step = group;
     if (my_step < step) my_step += ((step - my_step + groups - 1) / groups) * groups;
     double beta = 0.0;
     double ep_v = 0.0, ep_r = 0.0;       // LIGHT: the epilogue's operands, fetched ahead of the sweep
@@ -1382,7 +1387,7 @@ void seg_finalize(SegView *sv)
     sv->div_shift = s - 1;
 }
 
-GemvPlan plan_gemv(int variant, int rows, int n, long lda)
+GemvPlan plan_gemv(int variant, int rows, int n, long lda, bool allow_split)
 {
     GemvPlan pl{};
     pl.split = 1;
@@ -1404,7 +1409,14 @@ GemvPlan plan_gemv(int variant, int rows, int n, long lda)
         //    the one-round form with 4 rows x 4 steps, 155.5 us against 157.8 on 4096 x 32768 and 306.7 against 309.2
         //    on 8192 x 32768 (profiles/r02_k1_shards/); up to 16384 rows the one-round form of (8,2): 605.2 against 608.5.
         if (rows >= 2048 && block_bytes > 256.0 * 1024 * 1024) {
-            if (rows <= 8192) { pl.R = 4; pl.U = 4; pl.light = 1; }
+            if (rows <= 16384 && allow_split) {
+                // the consumer adds the column pieces itself (fused P2P update): (8,2) one-round form, pieces tied to the
+                // XCDs, as many as keep the p.Ap partials of the rank at <= 4096 (what K3 folds on one GPU today)
+                pl.R = 8; pl.U = 2; pl.light = 1;
+                const int groups = (rows + 7) / 8;
+                pl.split = groups <= 512 ? 8 : (groups <= 1024 ? 4 : (groups <= 2048 ? 2 : 1));
+            }
+            else if (rows <= 8192) { pl.R = 4; pl.U = 4; pl.light = 1; }
             else if (rows <= 16384) { pl.R = 8; pl.U = 2; pl.light = 1; }
             else { pl.R = 8; pl.U = 2; }
         }
