@@ -172,3 +172,18 @@ def test_bench_survives_a_wireup_stage_that_never_returns(gpu_pkg):
     assert set(c["transport_calibration_ms_per_iteration"]) == {"p2p", "p2p-sep"}
     assert any("rccl" in note and "did not finish within 3 s" in note for note in c["transport_notes"])
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_bench_two_ranks_n32768_default_column_split(gpu_pkg, oracle):
+    """The strong-scaling workload itself with two ranks sharing the GPU: each rank's 16384 x 32768 shard streams from HBM,
+    so the fused P2P transport runs K1 with its default XCD-affine column split (2 pieces at P = 2) and the update adds the
+    pieces on the fly.  Residual after 25 iterations against the oracle's on-the-fly twin with the same partition."""
+    n = 32768
+    r = torchrun(2, 29727, ["--steps", "20", "--warmup", "5", "--transport", "p2p", "--no-solve-window"], env={"CGX_BENCH_BACKEND": "gloo"}, timeout=600)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    d = one_line(r.stdout)
+    assert d["n_gpus"] == 2 and d["config"]["transport"] == "p2p" and d["config"]["n"] == n and d["iterations_done"] == 25
+    assert [q["rows"] for q in d["k1_per_rank"]] == [16384, 16384]
+    assert d["roofline"]["traffic"] is not None and d["roofline"]["consistency"] == "ok"
+    _, ro = oracle.solve_lap2d_banded(n, 25, 0.0, 2)
+    assert abs(d["residual_after_run"] - ro["residual_prev"]) <= 1e-6 * ro["residual_prev"]
