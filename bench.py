@@ -66,11 +66,13 @@ def parse_args():
     return ap.parse_args()
 
 
-def pmc_traffic(n, nranks):
-    """HBM bytes per K1 launch from a committed rocprofv3 --pmc pass (profiles/), or None."""
+def pmc_traffic(n, nranks, transport="p2p"):
+    """HBM bytes per K1 launch from a committed rocprofv3 --pmc pass (profiles/), or None.  On shards the fused P2P
+    transport runs the column-split K1 ("rows"), the other transports the unsplit one ("rows_unsplit_shards")."""
     path = os.path.join(ROOT, TRAFFIC_FILE)
     try:
-        rows = json.load(open(path))["rows"]
+        doc = json.load(open(path))
+        rows = doc["rows"] if (transport == "p2p" or nranks == 1) else doc.get("rows_unsplit_shards", [])
     except Exception:
         return None
     for r in rows:
@@ -530,7 +532,7 @@ class Bench:
         slowest = max(timed_ranks, key=lambda r: r["median_ms"]) if timed_ranks else None
         roof = {
             "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
-            "traffic": pmc_traffic(n, world),
+            "traffic": pmc_traffic(n, world, transport),
             "traffic_source": "committed rocprofv3 --pmc pass, %s (FETCH_SIZE x2 + WRITE_SIZE per the guide's gfx950 "
                               "correction); NOT a counter of this run" % TRAFFIC_FILE,
             "kernel": "k_gemv (K1, A.p of this rank's row block)",
