@@ -2,8 +2,10 @@
 """bench.py -- CG iterations/s and K1 HBM-roofline fraction on MI355X (BASELINE.json metric).
 
     python bench.py                       # 1 GPU, generate_lap2d N=32768, 500 timed iterations (configs[2])
+    python bench.py --gpus N --steps K --warmup W       # row-block over N GPUs (configs[3], strong scaling): starts its
+                                                        # own N ranks (one fresh child process per GPU, see self_launch)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W          # row-block over N GPUs (configs[3], strong scaling)
+        bench.py --gpus N --steps K --warmup W          # the same under an external launcher (RANK / WORLD_SIZE set)
 
 A "step" is one body of the CG loop (code/MPI/cg.cc:96-137 of the reference): one A.p GEMV over this
 rank's row block, two dot products, the x/r/p updates and the exchanges (here: ONE per iteration).  Inputs are synthetic and
@@ -17,7 +19,7 @@ Extra objects in the line:
                   divided by the MEDIAN launch duration of the timed region, measured with HIP events bound to the K1
                   dispatches on the library's own stream (the first launch after the sync is never a sample).
   cpu_baseline -- the CPU oracle (oracle/cg_oracle.c, a port of the reference's serial path) run for a few
-                  iterations of the same workload on one host core (rank 0, 1-GPU runs only).
+                  iterations of the same workload on one host core (rank 0, after the timed region, at any N).
   solve_window -- the same K iterations through the reference's own timing window (all of solve(), cg_main.cc:53-55).
 
 Rank 0 ALWAYS prints a line: if no transport produces a result, if an exception escapes, or if a watchdog expires, the line
@@ -28,6 +30,8 @@ import json
 import math
 import os
 import signal
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -66,17 +70,19 @@ def parse_args():
     return ap.parse_args()
 
 
-def pmc_traffic(n, nranks, transport="p2p"):
-    """HBM bytes per K1 launch from a committed rocprofv3 --pmc pass (profiles/), or None.  On shards the fused P2P
-    transport runs the column-split K1 ("rows"), the other transports the unsplit one ("rows_unsplit_shards")."""
+def pmc_traffic(n, nranks, plan):
+    """HBM bytes per K1 launch from a committed rocprofv3 --pmc pass (profiles/), or None.  A row counts only if it was
+    collected on the SAME K1 form (R, U, light, split as the library reports them for this run) at the same n and shard
+    count: a counter file of another kernel is no evidence for this one."""
     path = os.path.join(ROOT, TRAFFIC_FILE)
     try:
-        doc = json.load(open(path))
-        rows = doc["rows"] if (transport == "p2p" or nranks == 1) else doc.get("rows_unsplit_shards", [])
+        rows = json.load(open(path))["rows"]
     except Exception:
         return None
+    want = {k: int(plan[k]) for k in ("R", "U", "light", "split")} if plan else None
     for r in rows:
-        if r.get("n") == n and r.get("nranks") == nranks:
+        if r.get("n") == n and r.get("nranks") == nranks and want is not None and \
+                {k: int(r.get("plan", {}).get(k, -1)) for k in want} == want:
             return r.get("hbm_bytes_per_launch")
     return None
 
@@ -115,9 +121,15 @@ def call_with_timeout(fn, seconds, what):
     return box.get("value")
 
 
+def cpu_baseline_iters(n, asked):
+    """Loop bodies to time: the asked count at N <= 32768, fewer above (the cost of one body grows with N^2), at least 3."""
+    return max(3, min(asked, int(asked * (32768.0 / n) ** 2))) if n > 32768 else asked
+
+
 def cpu_baseline(n, iters):
     import __graft_entry__ as g
     O = g.load_oracle()
+    iters = cpu_baseline_iters(n, iters)
     t0 = time.time()
     _, r = O.solve_lap2d(n, iters, 0.0, 1)     # tol 0: never converges, exactly `iters` loop bodies
     wall = time.time() - t0
@@ -239,6 +251,11 @@ class Bench:
 
         assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path to time"
         ndev = torch.cuda.device_count()
+        self.backend = os.environ.get("CGX_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of world > 1 on a one-GPU box
+        if world > ndev and self.backend == "nccl":
+            # every rank sees the same count and leaves here, before any rendezvous: a clean failure line, not a hang
+            raise RuntimeError("bench.py --gpus %d needs %d MI355X, %d visible here (CGX_BENCH_BACKEND=gloo rehearses several "
+                               "ranks on one GPU over the IPC mailboxes)" % (world, world, ndev))
         if self.local_rank >= ndev:
             # more ranks than GPUs is only ever a rehearsal on a one-GPU box (RCCL itself refuses duplicate devices)
             self.local_rank = self.local_rank % ndev
@@ -250,7 +267,6 @@ class Bench:
         self.use_comm = world > 1 or ("RANK" in os.environ and os.environ.get("CGX_BENCH_FORCE_SELF") != "1")
         if self.use_comm:
             import torch.distributed as dist
-            self.backend = os.environ.get("CGX_BENCH_BACKEND", "nccl")   # "gloo": rehearsal of world > 1 on a one-GPU box
 
             def init_pg():
                 if self.backend == "nccl":
@@ -471,6 +487,12 @@ class Bench:
             cand = self.make_solver(tname)
             if cand is not None:
                 solvers[tname] = cand
+        # what the RCCL candidate spans (ncclCommCount on every rank), recorded while it exists: the calibration may hand the
+        # timed run to the mailboxes, and the line must still say whether RCCL saw all N ranks (cg.cc:50-51)
+        self.rccl_nranks = None
+        if "rccl" in solvers:
+            counts = self.gather_rows([float(solvers["rccl"].comm_info()["ranks_wired"])])
+            self.rccl_nranks = int(min(c[0] for c in counts))
         self.state["stage"] = "pre-warm"
         for tname, cand in list(solvers.items()):
             if not self.prewarm(cand, tname):
@@ -514,6 +536,9 @@ class Bench:
         info = solver.comm_info()
         devices = self.gather_strings(info["device_id"])
         wired = self.gather_rows([info["ranks_wired"], info["rank_seen"]])
+        plan = solver.gemv_plan()
+        plan_keys = ("variant", "R", "U", "waves", "light", "split", "grid", "ncols")
+        plans = [dict(zip(plan_keys, (int(v) for v in row))) for row in self.gather_rows([float(plan[k]) for k in plan_keys])]
 
         self.state["stage"] = "solve-window run"
         window = None if args.no_solve_window else self.solve_window(solver, args.steps)
@@ -532,9 +557,10 @@ class Bench:
         slowest = max(timed_ranks, key=lambda r: r["median_ms"]) if timed_ranks else None
         roof = {
             "bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None,
-            "traffic": pmc_traffic(n, world, transport),
-            "traffic_source": "committed rocprofv3 --pmc pass, %s (FETCH_SIZE x2 + WRITE_SIZE per the guide's gfx950 "
-                              "correction); NOT a counter of this run" % TRAFFIC_FILE,
+            "traffic": None,
+            "traffic_source": "committed rocprofv3 --pmc pass of the same K1 form (config.k1_plan) at this n and shard count, "
+                              "%s (FETCH_SIZE x2 + WRITE_SIZE per the guide's gfx950 correction); NOT a counter of this "
+                              "run; null when no committed row matches the plan that ran" % TRAFFIC_FILE,
             "kernel": "k_gemv (K1, A.p of this rank's row block)",
             "timing": "HIP events bound to the K1 dispatch (kernel begin/end) on the library's stream, every %s launch "
                       "of the timed region, median; the first launch after the sync is not sampled"
@@ -548,6 +574,7 @@ class Bench:
                 "launches_timed": lim["launches_timed"], "launches_discarded": lim["launches_discarded"],
                 "rank": lim["rank"], "consistency": "ok" if ok else "violated",
             })
+            roof["traffic"] = pmc_traffic(n, world, plans[lim["rank"]])
             if ok:
                 roof["achieved"] = lim["GBs"]
                 roof["frac"] = lim["GBs"] / HBM_PEAK_GBS
@@ -570,7 +597,10 @@ class Bench:
             "prewarm_iterations": self.prewarm_iterations.get(transport),   # untimed, before the W warm-up steps
             # what the transports really span (from the transports, not from the flags)
             "process_group_ranks": self.dist.get_world_size() if self.dist is not None else 1,
-            "rccl_nranks": int(wired[0][0]) if transport == "rccl" else None,      # ncclCommCount of the library's communicator
+            # ncclCommCount of the library's RCCL communicator (min over ranks): of the transport that ran, or of the RCCL
+            # candidate of the calibration when the mailboxes carried the timed run; None if no RCCL communicator was built
+            "rccl_nranks": int(wired[0][0]) if transport == "rccl" else self.rccl_nranks,
+            "k1_plan": plans if world > 1 else plans[0],     # the K1 form the library ran on every rank (cgx_get_gemv_plan)
             "transport_ranks_wired": [int(w[0]) for w in wired],
             "ranks_seen": len(k1_rows),                                            # ranks whose results were compared bit for bit
             "distinct_gpus": len(set(devices)), "gpu_pci_ids": devices,
@@ -597,7 +627,8 @@ class Bench:
         # for a reader of a GPU-utilisation sampler beside this line: how much device work the process did in all (the
         # rest of a 1-GPU run's wall time is the CPU baseline, which keeps the GPU idle)
         line["gpu_work"] = {"seconds_in_timed_loops": self.gpu_work_s, "cg_iterations_on_device": self.gpu_iterations}
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
+            # rank 0 only, after the timed region and outside every bracket; the other ranks wait at the teardown barrier
             self.state["stage"] = "cpu baseline"
             line["cpu_baseline"] = cpu_baseline(n, args.cpu_baseline_iters)
         return line
@@ -608,6 +639,67 @@ class Bench:
         if self.dist is not None:
             self.dist.barrier()
             self.dist.destroy_process_group()
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+LAUNCHED = {"proc": None}      # the launcher child of self_launch, for the watchdog / SIGTERM paths to stop
+
+
+def stop_launched():
+    """End the launcher child and every rank under it (its own process group), if there is one."""
+    proc = LAUNCHED["proc"]
+    if proc is None or proc.poll() is not None:
+        return
+    for sig, wait in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 5.0)):
+        try:
+            os.killpg(proc.pid, sig)
+        except (ProcessLookupError, PermissionError):
+            return
+        try:
+            proc.wait(wait)
+            return
+        except subprocess.TimeoutExpired:
+            pass
+
+
+def self_launch(args, emit_raw, failure_line, state):
+    """`python bench.py --gpus N` with no launcher around it (RANK / WORLD_SIZE unset): this process becomes the launcher.
+    It starts `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a FRESH CHILD process --
+    before torch is imported or HIP is touched here, and never by exec -- relays the one JSON line rank 0 prints, passes
+    stderr through, and leaves with the child's exit code.  (The reference gets its ranks from `srun -n P`,
+    code/MPI/cg_main.cc:15-20 and cg.run:15-19; the GPU box has no such launcher by itself.)  Returns the exit code."""
+    state["stage"] = "self-launch of %d ranks" % args.gpus
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    print("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=None, env=env, start_new_session=True)
+    LAUNCHED["proc"] = proc
+    relayed = False
+    for raw in proc.stdout:                       # ends when every holder of the pipe has closed it
+        text = raw.decode(errors="replace").strip()
+        if not relayed and text.startswith("{"):
+            try:
+                ok = "metric" in json.loads(text)
+            except ValueError:
+                ok = False
+            if ok:
+                relayed = emit_raw(text)
+                continue
+        if text:
+            print(text, file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if not relayed:
+        emit_raw(json.dumps(failure_line("launch", "the %d ranks started by bench.py ended with exit code %d without a result "
+                                                   "line (see stderr)" % (args.gpus, rc))))
+        rc = rc or 1
+    return rc
 
 
 def main():
@@ -626,13 +718,17 @@ def main():
     state = {"stage": "start", "printed": False}
     lock = threading.Lock()
 
-    def emit(line):
+    def emit_raw(text):
         """Rank 0 prints exactly one line, whoever gets here first (main thread, watchdog or signal handler)."""
         with lock:
             if rank != 0 or state["printed"]:
-                return
+                return False
             state["printed"] = True
-            os.write(json_fd, (json.dumps(line) + "\n").encode())
+            os.write(json_fd, (text + "\n").encode())
+            return True
+
+    def emit(line):
+        emit_raw(json.dumps(line))
 
     def failure_line(kind, message):
         line = base_line(args, max(world, args.gpus), problem_size(args, max(world, args.gpus)))
@@ -641,6 +737,7 @@ def main():
 
     def on_watchdog():
         printed = state["printed"]
+        stop_launched()
         emit(failure_line("watchdog", "no result after %.0f s" % args.watchdog))
         print("bench.py rank %d: watchdog expired in stage '%s'" % (rank, state["stage"]), file=sys.stderr, flush=True)
         os._exit(0 if printed else 3)
@@ -649,22 +746,30 @@ def main():
         # SIGTERM is what the launcher sends when another rank died.  A Python-level handler would only run once the
         # main thread is back from whatever C call it is blocked in, so a dedicated thread waits for the signal.
         signum = signal.sigwait({signal.SIGTERM})
+        stop_launched()
         emit(failure_line("signal", "received signal %d (the launcher stops this rank: another rank failed?)" % signum))
         os._exit(4)
 
     signal.pthread_sigmask(signal.SIG_BLOCK, {signal.SIGTERM})   # before any thread exists: every thread inherits the mask
     threading.Thread(target=wait_for_sigterm, daemon=True, name="bench-sigterm").start()
-    dog = threading.Timer(args.watchdog, on_watchdog)
+    launcher = args.gpus > 1 and "RANK" not in os.environ and "WORLD_SIZE" not in os.environ
+    # the ranks run their own watchdog of args.watchdog seconds and print their own failure line; the launching parent's is
+    # the backstop behind it
+    dog = threading.Timer(args.watchdog + (60.0 if launcher else 0.0), on_watchdog)
     dog.daemon = True
     dog.start()
 
+    if launcher:
+        rc = 1
+        try:
+            rc = self_launch(args, emit_raw, failure_line, state)
+        except BaseException as e:           # noqa: BLE001 -- the line must still come out
+            traceback.print_exc(file=sys.stderr)
+            stop_launched()
+            emit(failure_line(type(e).__name__, e))
+        sys.stderr.flush()
+        os._exit(rc)
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            emit(failure_line("launch", "bench.py --gpus %d must be launched with torch.distributed.run "
-                                        "--nproc-per-node %d" % (args.gpus, args.gpus)))
-            print("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                  % (args.gpus, args.gpus), file=sys.stderr)
-            os._exit(2)
         args.gpus = world
 
     b = Bench(args, world, rank, local_rank, state)

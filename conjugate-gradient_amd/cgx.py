@@ -21,7 +21,7 @@ MAX_DIAGONALS = 64
 
 EXPORTS = [
     "cgx_config_init", "cgx_comm_unique_id", "cgx_create", "cgx_destroy", "cgx_last_error", "cgx_status_string",
-    "cgx_get_comm_info", "cgx_p2p_export", "cgx_p2p_import", "cgx_p2p_selftest",
+    "cgx_get_comm_info", "cgx_get_gemv_plan", "cgx_p2p_export", "cgx_p2p_import", "cgx_p2p_selftest",
     "cgx_partition", "cgx_generate_lap2d_matrix", "cgx_set_matrix_dense", "cgx_read_matrix",
     "cgx_init_source_term", "cgx_set_source_term", "cgx_set_max_iter", "cgx_set_tolerance", "cgx_get_size",
     "cgx_get_matrix_format",
@@ -93,6 +93,7 @@ def lib():
         L.cgx_status_string.argtypes = [C.c_int]
         L.cgx_status_string.restype = C.c_char_p
         L.cgx_get_comm_info.argtypes = [vp, ip, ip, ip, C.c_char_p]
+        L.cgx_get_gemv_plan.argtypes = [vp, C.c_int, ip]
         L.cgx_p2p_export.argtypes = [vp, C.POINTER(C.c_ubyte)]
         L.cgx_p2p_import.argtypes = [vp, C.POINTER(C.c_ubyte)]
         L.cgx_p2p_selftest.argtypes = [vp, C.c_int, ip]
@@ -216,6 +217,12 @@ class CGSolver:
         self._check(lib().cgx_get_comm_info(self._h, C.byref(mode), C.byref(wired), C.byref(seen), dev))
         return {"comm_mode": mode.value, "ranks_wired": wired.value, "rank_seen": seen.value,
                 "device_id": dev.value.decode(errors="replace")}
+
+    def gemv_plan(self, local_shard=0):
+        """The K1 launch shape of a local shard (cgx_get_gemv_plan): which kernel form runs on it."""
+        v = (C.c_int * 8)()
+        self._check(lib().cgx_get_gemv_plan(self._h, int(local_shard), v))
+        return dict(zip(("variant", "R", "U", "waves", "light", "split", "grid", "ncols"), list(v)))
 
     # -- direct peer exchange wire-up (COMM_P2P) ------------------------------------------------------
     def p2p_export(self):

@@ -410,6 +410,15 @@ cgx_status cgx_get_comm_info(cgx_ctx *ctx, int *comm_mode, int *ranks_wired, int
     return CGX_OK;
 }
 
+cgx_status cgx_get_gemv_plan(const cgx_ctx *ctx, int local_shard, int out[CGX_GEMV_PLAN_INTS])
+{
+    if (!ctx || !out || local_shard < 0 || local_shard >= (int)ctx->shards.size()) return CGX_ERR_BAD_ARG;
+    const cgx::GemvPlan &pl = ctx->shards[(size_t)local_shard].plan;
+    const int v[CGX_GEMV_PLAN_INTS] = {pl.variant, pl.R, pl.U, pl.waves, pl.light, pl.split, pl.grid, pl.ncols};
+    memcpy(out, v, sizeof v);
+    return CGX_OK;
+}
+
 cgx_status cgx_p2p_export(cgx_ctx *ctx, unsigned char out[CGX_IPC_HANDLE_BYTES])
 {
     static_assert(sizeof(hipIpcMemHandle_t) == CGX_IPC_HANDLE_BYTES, "hipIpcMemHandle_t size");

@@ -132,6 +132,13 @@ const char *cgx_status_string(cgx_status s);
  *                 distinct GPUs behind its ranks; at least 32 bytes, may be NULL. */
 cgx_status  cgx_get_comm_info(cgx_ctx *ctx, int *comm_mode, int *ranks_wired, int *rank_seen, char *device_id);
 
+/* The K1 (GEMV, cg.cc:100-102) launch shape the library planned for local shard `local_shard` of the current problem,
+ * for the benchmark record (which kernel ran): out = {variant (1 column-split, 2 LDS-staged p tiles, 3 banded), R rows per
+ * workgroup (variant 2: per wave), U steps in flight, waves per workgroup, light (1 = the one-round form), split (column
+ * pieces per row group, tied to the XCDs), grid (workgroups of one fused launch), ncols (columns swept)}. */
+#define CGX_GEMV_PLAN_INTS 8
+cgx_status  cgx_get_gemv_plan(const cgx_ctx *ctx, int local_shard, int out[CGX_GEMV_PLAN_INTS]);
+
 /* ---- CGX_COMM_P2P wire-up (replaces MPI_Init's job for the direct-xGMI transport) --------- */
 /* export: this rank's mailbox as an IPC handle.  import: all ranks' handles, rank order (nranks * 64 bytes),
  * gathered by the launcher (torch.distributed, MPI_Allgather, pipes ...).  selftest: `rounds` all-gathers of

@@ -37,12 +37,89 @@ def test_failure_line_without_a_device():
     assert d["error"]["kind"] == "AssertionError" and "no CPU path" in d["error"]["message"]
 
 
-def test_failure_line_when_launched_without_the_launcher():
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "4"], capture_output=True, text=True, timeout=120, env=no_gpu_env())
+def test_self_launch_without_a_device_relays_rank0s_failure_line():
+    """`python bench.py --gpus 4` with no launcher around it starts its own four ranks (fresh child processes, torch never
+    imported in the parent), every rank fails for lack of a device, and the parent relays rank 0's ONE line and the
+    child's exit code (code/MPI/cg_main.cc:15-20: the reference's ranks come from srun)."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--steps", "7", "--warmup", "2"], capture_output=True, text=True,
+                       timeout=300, env=no_gpu_env())
     d = one_line(r.stdout)
-    assert r.returncode == 2 and d["value"] is None and d["n_gpus"] == 4
-    assert d["error"]["kind"] == "launch" and "--nproc-per-node 4" in d["error"]["message"]
+    assert r.returncode != 0 and d["value"] is None and d["n_gpus"] == 4 and d["steps"] == 7 and d["warmup"] == 2
+    assert d["error"]["kind"] == "AssertionError" and "no CPU path" in d["error"]["message"]
     assert "configs[3]" in d["config"]["workload"] and d["config"]["parallelism"] == "rowblock4"
+    assert "starting 4 ranks" in r.stderr and "--nproc-per-node 4" in r.stderr
+
+
+def test_self_launch_is_skipped_under_a_launcher():
+    """With RANK / WORLD_SIZE in the environment bench.py is a rank, never a launcher (the driver's N > 1 command)."""
+    env = dict(no_gpu_env(), RANK="0", LOCAL_RANK="0", WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29655")
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "5", "--warmup", "1"], capture_output=True, text=True,
+                       timeout=300, env=env)
+    d = one_line(r.stdout)
+    assert d["value"] is None and d["n_gpus"] == 2 and "starting" not in r.stderr
+
+
+def test_self_launch_parent_prints_a_line_when_the_ranks_print_none(tmp_path):
+    """The ranks die without a word (here: the python the parent starts cannot run torch.distributed.run at all): the
+    parent still prints one failure line and a non-zero exit code."""
+    import bench
+    args = type("A", (), {"gpus": 2, "steps": 5, "warmup": 1, "mode": "strong", "n": 0})()
+    out = []
+    old_exe, old_argv = sys.executable, sys.argv
+    sys.executable, sys.argv = "/bin/false", ["bench.py", "--gpus", "2"]
+    try:
+        rc = bench.self_launch(args, lambda t: out.append(t) or True,
+                               lambda kind, msg: dict(bench.base_line(args, 2, 32768), error={"kind": kind, "message": msg}), {})
+    finally:
+        sys.executable, sys.argv = old_exe, old_argv
+    assert rc != 0 and len(out) == 1
+    d = json.loads(out[0])
+    assert d["value"] is None and d["error"]["kind"] == "launch" and "without a result line" in d["error"]["message"]
+
+
+def test_self_launch_watchdog_stops_the_ranks():
+    """The parent's watchdog (the backstop behind the ranks' own) ends the launcher child and its whole process group."""
+    import bench
+    proc = subprocess.Popen([sys.executable, "-c", "import subprocess, sys, time; "
+                             "subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(600)']); time.sleep(600)"],
+                            start_new_session=True)
+    time.sleep(1.0)
+    kids = subprocess.run(["pgrep", "-g", str(proc.pid)], capture_output=True, text=True).stdout.split()
+    assert len(kids) == 2
+    bench.LAUNCHED["proc"] = proc
+    try:
+        t0 = time.time()
+        bench.stop_launched()
+        assert proc.poll() is not None and time.time() - t0 < 20
+        time.sleep(0.5)
+        # nothing of the group is left running (an orphan nobody reaps may linger as a zombie in a container)
+        left = subprocess.run(["ps", "-o", "stat=", "-g", str(proc.pid)], capture_output=True, text=True).stdout.split()
+        assert all(st.startswith("Z") for st in left), left
+    finally:
+        bench.LAUNCHED["proc"] = None
+
+
+def test_cpu_baseline_sample_is_bounded_at_every_size():
+    import bench
+    assert bench.cpu_baseline_iters(32768, 20) == 20 and bench.cpu_baseline_iters(4096, 20) == 20
+    assert bench.cpu_baseline_iters(46340, 20) == 10          # configs[4], P = 8: half the bodies at twice the cost
+    assert bench.cpu_baseline_iters(131072, 20) == 3
+
+
+def test_traffic_row_must_match_the_plan_that_ran(tmp_path, monkeypatch):
+    import bench
+    doc = {"rows": [{"n": 32768, "nranks": 8, "plan": {"R": 8, "U": 2, "light": 1, "split": 8}, "hbm_bytes_per_launch": 123.0},
+                    {"n": 32768, "nranks": 1, "plan": {"R": 8, "U": 2, "light": 0, "split": 1}, "hbm_bytes_per_launch": 456.0}]}
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "profiles" / "k1_hbm_traffic.json").write_text(json.dumps(doc))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    plan8 = {"variant": 1, "R": 8, "U": 2, "waves": 4, "light": 1, "split": 8, "grid": 4096, "ncols": 32768}
+    assert bench.pmc_traffic(32768, 8, plan8) == 123.0
+    assert bench.pmc_traffic(32768, 8, dict(plan8, split=4)) is None          # another kernel form: no evidence
+    assert bench.pmc_traffic(32768, 8, dict(plan8, R=4, U=4, split=1)) is None
+    assert bench.pmc_traffic(32768, 1, dict(plan8, light=0, split=1)) == 456.0
+    assert bench.pmc_traffic(16384, 1, dict(plan8, light=0, split=1)) is None
+    assert bench.pmc_traffic(32768, 8, None) is None
 
 
 def test_watchdog_line():

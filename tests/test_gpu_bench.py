@@ -72,6 +72,7 @@ def test_bench_short_window_statistics(gpu_pkg, oracle):
     assert abs(d["residual_after_run"] - ro["residual_prev"]) <= 1e-6 * ro["residual_prev"]
     c = d["config"]
     assert c["transport"] == "self" and c["ranks_seen"] == 1 and c["distinct_gpus"] == 1 and c["rccl_nranks"] is None
+    assert c["k1_plan"]["variant"] == 1 and c["k1_plan"]["split"] == 1 and c["k1_plan"]["grid"] == n // c["k1_plan"]["R"]
 
 
 def test_bench_rccl_one_rank_under_the_launcher(gpu_pkg, oracle):
@@ -138,6 +139,7 @@ def test_bench_auto_transport_one_rank_under_the_launcher(gpu_pkg):
     assert set(c["transport_calibration_ms_per_iteration"]) == {"p2p", "p2p-sep", "rccl"}
     assert c["transport"] in ("p2p", "p2p-sep", "rccl") and c["transport_notes"] is None
     assert c["transport"] == min(c["transport_calibration_ms_per_iteration"], key=c["transport_calibration_ms_per_iteration"].get)
+    assert c["rccl_nranks"] == 1          # from the RCCL candidate of the calibration, whichever transport carried the run
     assert d["value"] > 0 and d["roofline"]["consistency"] == "ok" and d["roofline"]["launches_timed"] == 19
 
 
@@ -179,11 +181,46 @@ def test_bench_two_ranks_n32768_default_column_split(gpu_pkg, oracle):
     so the fused P2P transport runs K1 with its default XCD-affine column split (2 pieces at P = 2) and the update adds the
     pieces on the fly.  Residual after 25 iterations against the oracle's on-the-fly twin with the same partition."""
     n = 32768
-    r = torchrun(2, 29727, ["--steps", "20", "--warmup", "5", "--transport", "p2p", "--no-solve-window"], env={"CGX_BENCH_BACKEND": "gloo"}, timeout=600)
+    r = torchrun(2, 29727, ["--steps", "20", "--warmup", "5", "--transport", "p2p", "--no-solve-window", "--cpu-baseline-iters", "3"],
+                 env={"CGX_BENCH_BACKEND": "gloo"}, timeout=600)
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
     d = one_line(r.stdout)
     assert d["n_gpus"] == 2 and d["config"]["transport"] == "p2p" and d["config"]["n"] == n and d["iterations_done"] == 25
     assert [q["rows"] for q in d["k1_per_rank"]] == [16384, 16384]
+    plans = d["config"]["k1_plan"]
+    assert len(plans) == 2 and all(pl["light"] == 1 and pl["split"] >= 2 and pl["R"] == 8 and pl["U"] == 2 for pl in plans)
+    cb = d["cpu_baseline"]                 # north_star: the CPU path timed in the same run, on multi-GPU lines too
+    assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "N=32768" in cb["sample"]
     assert d["roofline"]["traffic"] is not None and d["roofline"]["consistency"] == "ok"
     _, ro = oracle.solve_lap2d_banded(n, 25, 0.0, 2)
     assert abs(d["residual_after_run"] - ro["residual_prev"]) <= 1e-6 * ro["residual_prev"]
+
+
+def test_bench_self_launch_two_ranks(gpu_pkg, oracle):
+    """`python3 bench.py --gpus 2` with NO launcher around it: the parent starts the two ranks itself (fresh children before
+    any GPU call), relays rank 0's one line and the child's exit code (cg_main.cc:15-20, cg.run:15-19)."""
+    n = 4096
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--matrix-size", str(n), "--steps", "30", "--warmup", "5",
+                        "--cpu-baseline-iters", "3"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, CGX_BENCH_BACKEND="gloo"))
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    d = one_line(r.stdout)
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["ranks_seen"] == 2 and c["process_group_ranks"] == 2 and c["transport"] in ("p2p", "p2p-sep")
+    assert d["value"] > 0 and d["iterations_done"] == 35 and len(c["k1_plan"]) == 2 and "cpu_baseline" in d
+    _, ro = oracle.solve_lap2d(n, 35, 0.0, 2)
+    assert abs(d["residual_after_run"] - ro["residual_prev"]) <= 1e-6 * ro["residual_prev"]
+
+
+def test_bench_self_launch_refuses_more_ranks_than_gpus(gpu_pkg):
+    """Two ranks over RCCL's control plane on a one-GPU box: every rank leaves before any rendezvous, rank 0's failure line
+    says what is missing, the parent relays it and a non-zero exit code -- no hang."""
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a box with fewer GPUs than ranks")
+    env = {k: v for k, v in os.environ.items() if k != "CGX_BENCH_BACKEND"}
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--matrix-size", "4096", "--steps", "10", "--warmup", "2"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    d = one_line(r.stdout)
+    assert r.returncode != 0 and d["value"] is None and d["n_gpus"] == 2
+    assert "needs 2 MI355X, 1 visible" in d["error"]["message"]
