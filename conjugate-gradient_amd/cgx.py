@@ -27,7 +27,7 @@ EXPORTS = [
     "cgx_get_matrix_format",
     "cgx_solve", "cgx_solve_begin", "cgx_solve_steps", "cgx_solve_end", "cgx_get_gemv_samples",
     "cgx_probe_gemv", "cgx_probe_time_gemv", "cgx_probe_vector_ops", "cgx_probe_get_matrix_rows",
-    "cgx_probe_get_source_term", "cgx_probe_set_fault_after",
+    "cgx_probe_get_source_term", "cgx_probe_set_fault_after", "cgx_probe_set_resident_limit",
 ]
 
 
@@ -118,6 +118,7 @@ def lib():
         L.cgx_probe_get_matrix_rows.argtypes = [vp, C.c_int, dp, ip, ip]
         L.cgx_probe_get_source_term.argtypes = [vp, C.c_int, dp]
         L.cgx_probe_set_fault_after.argtypes = [vp, C.c_int]
+        L.cgx_probe_set_resident_limit.argtypes = [vp, C.c_int]
         for name in EXPORTS:
             fn = getattr(L, name)
             if fn.restype is C.c_int and name not in ("cgx_config_init",):
@@ -341,6 +342,10 @@ class CGSolver:
     def _set_fault_after(self, calls):
         """Error-path tests: the HIP call after `calls` more of this context fails (-1 = off)."""
         lib().cgx_probe_set_fault_after(self._h, int(calls))
+
+    def _set_resident_limit(self, workgroups):
+        """Test hook: bound of co-resident workgroups the fused P2P update may assume (0 = ask the runtime)."""
+        lib().cgx_probe_set_resident_limit(self._h, int(workgroups))
 
     def probe_source_term(self, local_shard=0):
         """The device copy of b (n doubles) of a local shard."""

@@ -56,6 +56,7 @@ void free_shard(Shard &s)
     (void)hipFree(s.rbuf);
     (void)hipFree(s.partials);
     (void)hipFree(s.ap_parts);
+    (void)hipFree(s.k1_scratch);
     (void)hipFree(s.sc);
     (void)hipFree(s.gathered);
     s = Shard{};
@@ -75,11 +76,12 @@ void free_problem(cgx_ctx *ctx)
     ctx->in_solve = false;
 }
 
-// Mailbox bytes before the segment channel: flag words, channel 0 (16-B slots) and channel 2 (kSlots doubles).
+// Mailbox bytes before the segment channel: flag words, chunk flag words, channel 0 (16-B slots) and channel 2 (kSlots doubles).
+static long p2p_flag_bytes() { return (long)cgx::kP2pChannels * cgx::kMaxRanks * cgx::kP2pFlagStride; }
+static long p2p_data0_off() { return p2p_flag_bytes() + (long)cgx::kMaxChunkFlags * 8; }
 long p2p_fixed_prefix(int nranks)
 {
-    return (long)cgx::kP2pChannels * cgx::kMaxRanks * cgx::kP2pFlagStride + 2L * nranks * 16 +
-           2L * nranks * (long)cgx::kSlots * 8;
+    return p2p_data0_off() + 2L * nranks * 16 + 2L * nranks * (long)cgx::kSlots * 8;
 }
 
 long default_lda(const cgx_ctx *ctx, int n)
@@ -134,25 +136,46 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
         const char *e = getenv("CGX_GEMV_VARIANT");
         if (e) variant = atoi(e);
     }
-    // the fused P2P update adds the column pieces of a split K1 on the fly; every other consumer would need a combine kernel
-    const bool allow_split = ctx->cfg.comm_mode == CGX_COMM_P2P && !ctx->cfg.p2p_separate_exchange && ctx->nranks > 1;
+    // Chunked exchange (cgx_kernels.hip "Chunks"): whoever consumes K1's Ap adds its column pieces and reduces one p.Ap
+    // partial per chunk of the slice -- k_prefold_ap in front of the exchange, or the pushers of the fused P2P update.  That is
+    // every multi-rank dense run and every fused P2P run; one GPU and banded storage keep K1's own partials in the tail.
+    const bool fused_p2p = ctx->cfg.comm_mode == CGX_COMM_P2P && !ctx->cfg.p2p_separate_exchange;
+    ctx->chunked = (ctx->nranks > 1 && !ctx->banded) || fused_p2p;
+    const bool allow_split = ctx->chunked && !ctx->banded && ctx->nranks > 1;
     auto plan_for = [&](int rows) {
         return ctx->banded ? cgx::plan_dia(rows, variant) : cgx::plan_gemv(variant, rows, ctx->n, ctx->lda, allow_split);
     };
-    ctx->npart = 1;
-    for (int q = 0; q < ctx->nranks; ++q) ctx->npart = std::max(ctx->npart, plan_for(ctx->num_rows[q]).grid);
-    if (ctx->cfg.comm_mode == CGX_COMM_P2P && n > 256 * cgx::kMaxVectorGrid)
-        return fail(ctx, CGX_ERR_UNSUPPORTED, "CGX_COMM_P2P handles at most 262144 rows (the update kernel with the exchange "
-                                              "inside works one row per thread); use CGX_COMM_RCCL");
+    int grid_max = 1;
+    for (int q = 0; q < ctx->nranks; ++q) grid_max = std::max(grid_max, plan_for(ctx->num_rows[q]).grid);
+    const int cpr = cgx::chunks_per_rank(ctx->seg_Sr);
+    ctx->npart = ctx->chunked ? cpr : grid_max;
+    if (fused_p2p) {
+        // The update kernel with the exchange inside works one row per thread and its workgroups wait for each other inside
+        // the kernel: all of them must be resident at once, and their flags must fit the mailbox's flag words.
+        int limit = 0;
+        HIP_TRY(ctx, cgx::update_xr_p2p_resident_limit(ctx->device, &limit));
+        if (ctx->resident_limit > 0) limit = ctx->resident_limit;
+        const long grid = ((long)n + 255) / 256;
+        if (grid > cgx::kMaxVectorGrid || grid > limit || (long)ctx->nranks * cpr > cgx::kMaxChunkFlags)
+            return fail(ctx, CGX_ERR_UNSUPPORTED,
+                        "CGX_COMM_P2P with the exchange folded into the update kernel: " + std::to_string(grid) + " workgroups (one row "
+                        "per thread) must be resident at once, the device keeps " + std::to_string(std::min(limit, cgx::kMaxVectorGrid)) +
+                        "; use p2p_separate_exchange or CGX_COMM_RCCL");
+    } else if (ctx->cfg.comm_mode == CGX_COMM_P2P && n > 256 * cgx::kMaxVectorGrid) {
+        return fail(ctx, CGX_ERR_UNSUPPORTED, "CGX_COMM_P2P handles at most 262144 rows; use CGX_COMM_RCCL");
+    }
     if (ctx->cfg.comm_mode == CGX_COMM_P2P) {
-        // mailbox layout of this problem: flags, then per channel [2 parities][nranks] slots
+        // mailbox layout of this problem: flags, chunk flags, then per channel [2 parities][nranks] slots
         // The small fixed-size channels come first, so that their place never depends on the problem; the
         // segment channel (1), whose slot size does, comes last.  A re-layout for a new problem size is then
         // safe without a launcher barrier: the last exchange of a solve is on channel 2, and a rank can finish
         // it only after every peer has pushed its channel-2 data, i.e. after every peer is done with channel 1.
-        const long slot[cgx::kP2pChannels] = {16, ((long)(ctx->seg_Sr + 1) * 8 + 15) / 16 * 16, (long)cgx::kSlots * 8};
+        // (Chunk flag words change their meaning with cpr, but only ever hold epochs of the past: a stale word can
+        // never satisfy a wait for a newer epoch.)
+        const long slot[cgx::kP2pChannels] = {16, ((long)(ctx->seg_Sr + ctx->npart + 1) * 8 + 15) / 16 * 16, (long)cgx::kSlots * 8};
         long off = p2p_fixed_prefix(ctx->nranks);
-        ctx->mv.data_off[0] = (long)cgx::kP2pChannels * cgx::kMaxRanks * cgx::kP2pFlagStride;
+        ctx->mv.cflag_off = p2p_flag_bytes();
+        ctx->mv.data_off[0] = p2p_data0_off();
         ctx->mv.slot_bytes[0] = slot[0];
         ctx->mv.data_off[2] = ctx->mv.data_off[0] + 2L * ctx->nranks * slot[0];
         ctx->mv.slot_bytes[2] = slot[2];
@@ -193,6 +216,10 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
         if (s.plan.split > 1) {
             HIP_TRY(ctx, hipMalloc(&s.ap_parts, (size_t)s.plan.split * ctx->seg_Sr * sizeof(double)));
             HIP_TRY(ctx, hipMemsetAsync(s.ap_parts, 0, (size_t)s.plan.split * ctx->seg_Sr * sizeof(double), ctx->stream));
+        }
+        if (ctx->chunked) {
+            HIP_TRY(ctx, hipMalloc(&s.k1_scratch, (size_t)(grid_max + 8) * sizeof(double)));
+            HIP_TRY(ctx, hipMemsetAsync(s.k1_scratch, 0, (size_t)(grid_max + 8) * sizeof(double), ctx->stream));
         }
         HIP_TRY(ctx, hipMalloc(&s.sc, sizeof(Scalars)));
         HIP_TRY(ctx, hipMalloc(&s.gathered, (size_t)cgx::kMaxRanks * cgx::kSlots * sizeof(double)));
@@ -374,7 +401,6 @@ cgx_status cgx_create(cgx_ctx **out, const cgx_config *cfg_in)
         ctx->mv.base[cfg.rank] = ctx->mailbox;
         if (cfg.nranks == 1) ctx->p2p_ready = true;
     }
-    if (const char *fa = getenv("CGX_FAULT_AFTER")) ctx->fault_after = atoi(fa);   // error-path tests only (cgx_internal.h)
     *out = ctx;
     return CGX_OK;
 }

@@ -29,6 +29,8 @@ struct Shard {
     double *apg = nullptr;       // nranks * S doubles: exchanged segments [Ap slice | p.Ap partials] (cgx::SegView apv)
     double *rbuf = nullptr;      // lda + kSlots doubles: the replicated r and its scalars (cgx::SegView rv, one segment)
     double *ap_parts = nullptr;  // plan.split > 1: split x seg_Sr doubles, the column pieces of the fused K1's Ap
+    double *k1_scratch = nullptr;   // chunked exchange: where K1's per-workgroup p.Ap partials go (only the gemv probe reads them;
+                                    // the segment tail then holds one partial per chunk of the slice instead)
     double *partials = nullptr;  // scratch: per-workgroup partial sums of K3 and of the setup kernels
     Scalars *sc = nullptr;
     double *gathered = nullptr;  // kMaxRanks * kSlots doubles (DEBUG scalars of all ranks)
@@ -36,7 +38,8 @@ struct Shard {
     cgx::SegView apv{}, rv{};
     int npartials = 0;
     double *Ap() const { return apg + (size_t)rank * apv.S; }          // this shard's Ap slice (K1 output)
-    double *k1_part() const { return Ap() + apv.Sr; }                   // this shard's p.Ap partials (segment tail)
+    double *tail() const { return Ap() + apv.Sr; }                      // this shard's segment tail: the p.Ap partials that travel
+    double *k1_part() const { return k1_scratch ? k1_scratch : tail(); }   // K1's per-workgroup p.Ap partials
 };
 
 
@@ -70,7 +73,11 @@ struct cgx_ctx {
     long long p2p_timeout_ticks = 0;         // 100 MHz wall-clock ticks
 
     int seg_S = 0, seg_Sr = 0;   // exchange segment geometry (equal for all ranks)
-    int npart = 0;               // K1 partials per rank in exchange 1 (max grid over ranks)
+    int npart = 0;               // p.Ap partials per rank in the segment tail: K1's workgroups (max grid over ranks), or, chunked,
+                                 // the chunks of a slice (cgx::chunks_per_rank(seg_Sr))
+    bool chunked = false;        // the tail holds one partial per chunk (cgx_kernels.hip "Chunks"): every multi-rank dense
+                                 // run and every fused P2P update; else K1's own partials (one GPU; banded storage)
+    int resident_limit = 0;      // > 0: test override of the co-residency bound of the fused P2P update (cgx_probe_set_resident_limit)
 
     // loopback pointer tables (device)
     double **d_gathered_ptrs = nullptr;
@@ -99,7 +106,7 @@ struct cgx_ctx {
     bool steps_ev_pending = false;
     double steps_device_ms = 0;
 
-    int fault_after = -1;     // >= 0: HIP_TRY calls left until one is made to fail (CGX_FAULT_AFTER, error-path tests only)
+    int fault_after = -1;     // >= 0: HIP_TRY calls left until one is made to fail (cgx_probe_set_fault_after, error-path tests only)
 
     std::string err;
 };
@@ -112,8 +119,9 @@ extern thread_local std::string g_create_error;   // error of the last failed cg
 double wall_now();
 cgx_status fail(cgx_ctx *ctx, cgx_status st, const std::string &msg);
 
-// Fault injection for the error-path tests (tools/leak_check.py, tests): with CGX_FAULT_AFTER=N in the environment of
-// cgx_create, the (N+1)-th HIP call of the context made through HIP_TRY is not made and reports hipErrorUnknown instead.
+// Fault injection for the error-path tests (tools/leak_check.py, tests): after cgx_probe_set_fault_after(ctx, N) the
+// (N+1)-th HIP call of the context made through HIP_TRY is not made and reports hipErrorUnknown instead.  Only the explicit
+// probe call arms it: nothing in a user's environment can make a production call fail.
 inline bool fault_due(cgx_ctx *ctx)
 {
     if (!ctx || ctx->fault_after < 0) return false;

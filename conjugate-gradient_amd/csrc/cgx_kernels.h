@@ -60,7 +60,8 @@ struct GemvPlan {
 };
 
 // Choose the K1 shape for a shard of `rows` x `n` held at pitch `lda` (variant 0 = default).  allow_split: the consumer of
-// Ap can add column pieces itself (the fused P2P update), so the default may cut the columns of a row group into pieces.
+// Ap adds column pieces itself (every multi-rank transport: launch_prefold_ap or the fused P2P update), so the default may
+// cut the columns of a row group into pieces.
 GemvPlan plan_gemv(int variant, int rows, int n, long lda, bool allow_split = false);
 
 // K1, plain form: Ap = A[rows x lda] * v ; partials[wg] = sum over the workgroup's rows of v_local[i]*Ap[i].
@@ -74,13 +75,20 @@ hipError_t launch_gemv_plain(const GemvPlan &plan, const double *A, long lda, in
 // e_start / e_stop (both or neither): bound to the dispatch itself (hipExtLaunchKernel), so their difference is the
 // kernel's own begin -> end as rocprofv3 sees it, with no marker packets on the stream.
 // plan.split > 1: Ap is the first of plan.split partial vectors, ap_stride doubles apart (piece s of the columns
-// writes Ap + s * ap_stride); the consumer adds them in ascending order (launch_combine_ap, or the fused P2P update).
+// writes Ap + s * ap_stride); the consumer adds them in ascending order (launch_prefold_ap, or the fused P2P update).
 hipError_t launch_gemv_fused(const GemvPlan &plan, const double *A, long lda, int rows, int row0,
                              const double *p_old, double *p_new, SegView seg, double *Ap, double *partials,
                              Scalars *sc, int k, double tol, hipStream_t s, hipEvent_t e_start = nullptr,
                              hipEvent_t e_stop = nullptr, long ap_stride = 0);
-// dst[i] = parts[i] + parts[stride + i] + ... (split terms, ascending), i < count
-hipError_t launch_combine_ap(const double *parts, int split, long stride, int count, double *dst, hipStream_t s);
+// Chunks of a rank's Ap slice (see "Chunks" in cgx_kernels.hip): kChunkRows consecutive rows, one workgroup each.
+constexpr int kChunkRows = 512;
+inline int chunks_per_rank(int Sr) { return (Sr + kChunkRows - 1) / kChunkRows; }
+// In front of the exchange of every multi-rank transport but the fused P2P update: dst[i] = parts[i] + parts[stride + i]
+// + ... (split terms, ascending; split == 1: parts == dst, nothing is stored), i < Sr, and tail[c] = the part of
+// p_sub . Ap_sub (cg.cc:105) of chunk c, p_loc = p_new + row0.  K3 then folds P x chunks_per_rank(Sr) partials instead
+// of every K1 workgroup's.
+hipError_t launch_prefold_ap(const double *parts, int split, long stride, int rows, int Sr, const double *p_loc, double *dst,
+                             double *tail, const Scalars *sc, hipStream_t s);
 
 // K3: p.Ap = fixed-order sum over all ranks q of the tail_count doubles at tail_off of segment q's tail;
 // alpha = rsold / max(p.Ap, rsold*1e-14); x_sub += alpha p_sub (own rows); r -= alpha Ap for ALL n rows (r is
@@ -157,11 +165,15 @@ hipError_t launch_dia_pack(const double *A, long lda, int n, int row0, int rows,
 // ---- direct peer exchange (CGX_COMM_P2P): a lean all-gather over IPC-mapped mailboxes ---------------------
 // Every rank owns one fine-grained mailbox; all ranks map all mailboxes.  Layout (identical on every rank):
 //   flags : [kP2pChannels][kMaxRanks] words, one 128-B line each   (flag[c][q] = last epoch rank q delivered on channel c)
+//   chunk flags : kMaxChunkFlags words of 8 B, word q*cpr + c = last epoch rank q delivered chunk c of its slice on
+//                 channel 1 through the fused update kernel (k_update_xr_p2p)
 //   data  : per channel c, [2 parities][nranks] slots of slot_bytes[c]
 constexpr int kP2pChannels = 3;          // 0 = unused, 1 = [Ap slice | p.Ap] segments, 2 = DEBUG scalars
 constexpr int kP2pFlagStride = 128;      // bytes between flag words
+constexpr int kMaxChunkFlags = 2048;     // nranks * chunks per rank <= this (262144 rows: 512 + nranks)
 struct MailboxView {
     unsigned char *base[kMaxRanks];      // base[q] = rank q's mailbox as mapped in THIS process (base[rank] = own)
+    long cflag_off;                      // byte offset of the chunk flag words
     long data_off[kP2pChannels];         // byte offset of channel c's data area
     long slot_bytes[kP2pChannels];       // bytes per (parity, rank) slot
     int nranks, rank;
@@ -178,15 +190,18 @@ hipError_t launch_mailbox_allgather(const MailboxView &mv, int chan, unsigned lo
                                     int count, int tail_off, int tail_n, double *dst, long dst_stride, int sum_off,
                                     int copy_self, long long timeout_ticks, int *err, hipStream_t s);
 
-// K3 with the iteration's exchange inside (CGX_COMM_P2P): workgroups 0..P-1 push [Ap slice | folded partial] to
-// their peer, every workgroup waits (bounded) for all flags and reads the Ap element of its row and the P scalars
-// straight from the mailbox.  The iteration is then K1 + this kernel.
-// ap_parts != nullptr: this rank's Ap slice exists only as `split` partial vectors (column pieces of K1), `stride` apart;
-// pushers and own rows add them up in ascending order on the fly.
-hipError_t launch_update_xr_p2p(int n, int rows, int row0, const double *p_new, SegView apv, int npart,
+// K3 with the iteration's exchange inside (CGX_COMM_P2P): the (peer, chunk) pairs are dealt over the workgroups, each
+// pushes [one chunk of the Ap slice | its p.Ap partial] into one peer's mailbox and raises that peer's chunk flag; every
+// workgroup waits (bounded) for all nranks x cpr flags and reads the Ap element of its row and the partials straight from
+// the mailbox.  The iteration is then K1 + this kernel.  ap_src: this rank's Ap slice as `split` column pieces of K1,
+// `stride` apart (split == 1: the whole slice), added up in ascending order on the fly.  cpr = chunks_per_rank(apv.Sr).
+hipError_t launch_update_xr_p2p(int n, int rows, int row0, const double *p_new, SegView apv, int cpr,
                                 const MailboxView &mv, int chan, unsigned long long epoch, double *x, SegView rv, Scalars *sc,
                                 int parity, long long timeout_ticks, int *err, hipStream_t s,
-                                const double *ap_parts = nullptr, int split = 1, long stride = 0);
+                                const double *ap_src, int split, long stride);
+// Workgroups of k_update_xr_p2p the device keeps resident at once (occupancy x CUs): its grid must not exceed this, since
+// its workgroups wait for each other inside the kernel.
+hipError_t update_xr_p2p_resident_limit(int device, int *workgroups);
 
 // Loopback "collective": copy local[kSlots] of every shard into gathered[] of every shard (<= 16 shards).
 hipError_t launch_loopback_gather(double *const *gathered_ptrs, const Scalars *const *scalar_ptrs, int nshards,

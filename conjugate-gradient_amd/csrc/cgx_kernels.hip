@@ -395,7 +395,8 @@ __global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 
             long er = row0 + (lane & (R - 1));
             if (er > rows - 1) er = rows - 1;
             if (er < 0) er = 0;
-            const int j = row0_global + (int)er;
+            int j = row0_global + (int)er;
+            if (j > ncols_all - 1) j = ncols_all - 1;   // shard without rows (N < P): row0_global == n; the value is never used
             ep_v = v[j];
             if constexpr (FUSED) ep_r = seg_load(sv, j);
         }
@@ -614,19 +615,50 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_ldsp(const double *__restri
     }
 }
 
-// The column pieces of a split K1 added up into the Ap slice (every consumer but the fused P2P update, which does it itself).
-__global__ __launch_bounds__(256) void k_combine_ap(const double *__restrict__ parts, int split, long stride, int count,
-                                                     double *__restrict__ dst)
+// ------------------------------------------------------------------------------------------------
+// Chunks.  Between K1 and the exchange a rank's Ap slice is handled in chunks of kChunkRows consecutive rows, one workgroup
+// each (a thread owns a pair of rows, so every access is 16 B).  For its pair a thread adds K1's column pieces in ascending
+// order (split == 1: the slice is already whole), and the workgroup reduces the chunk's part of p_sub . Ap_sub (cg.cc:105)
+// in one fixed order.  What travels between ranks is then [Ap slice | one p.Ap partial per chunk]: n/512 partials in all,
+// whatever the grid of K1 was -- K1's own per-workgroup partials (4096 per rank with the columns split 8 ways) are not
+// folded by anybody on a multi-GPU run.  Used by k_prefold_ap (RCCL, separate mailbox exchange, loopback) and by the
+// pushers of k_update_xr_p2p (fused exchange): the same code, the same bits on every transport.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ d2 chunk_pair(const double *__restrict__ parts, int split, long stride, int row, int Sr)
 {
-    const long i = ((long)blockIdx.x * 256 + threadIdx.x) * 2;
-    if (i >= count) return;
-    d2 a = *reinterpret_cast<const d2 *>(parts + i);            // count is padded to even, slices are 16-B aligned
-    for (int sp = 1; sp < split; ++sp) {
-        const d2 b = *reinterpret_cast<const d2 *>(parts + sp * stride + i);
-        a.x += b.x;
-        a.y += b.y;
+    d2 a{0.0, 0.0};
+    if (row < Sr) {                                                  // Sr is even, slices are 16-B aligned
+        a = *reinterpret_cast<const d2 *>(parts + row);
+        for (int sp = 1; sp < split; ++sp) {
+            const d2 b = *reinterpret_cast<const d2 *>(parts + sp * stride + row);
+            a.x += b.x;
+            a.y += b.y;
+        }
     }
-    *reinterpret_cast<d2 *>(dst + i) = a;
+    return a;
+}
+
+template <int WAVES>
+__device__ __forceinline__ double chunk_dot(const double *__restrict__ p_loc /* p_new + row0 */, d2 a, int row, int rows, double *lds)
+{
+    double d = 0.0;
+    if (row < rows) d = p_loc[row] * a.x;                            // row0 may be odd: 8-B loads
+    if (row + 1 < rows) d = fma(p_loc[row + 1], a.y, d);
+    return block_sum<WAVES>(d, lds);
+}
+
+// One workgroup per chunk, in front of the exchange: dst = the Ap slice of this rank's segment, tail = its chunk partials.
+__global__ __launch_bounds__(256) void k_prefold_ap(const double *__restrict__ parts, int split, long stride, int rows, int Sr,
+                                                     const double *__restrict__ p_loc, double *__restrict__ dst,
+                                                     double *__restrict__ tail, const Scalars *sc)
+{
+    __shared__ double lds[4];
+    if (sc->done) return;                                            // converged earlier (uniform): K3 will not look either
+    const int row = ((int)blockIdx.x * 256 + (int)threadIdx.x) * 2;
+    const d2 a = chunk_pair(parts, split, stride, row, Sr);
+    if (split > 1 && row < Sr) *reinterpret_cast<d2 *>(dst + row) = a;
+    const double d = chunk_dot<4>(p_loc, a, row, rows, lds);
+    if (threadIdx.x == 0) tail[blockIdx.x] = d;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1233,21 +1265,25 @@ __global__ __launch_bounds__(256) void k_mailbox_allgather(MailboxView mv, int c
 
 // ------------------------------------------------------------------------------------------------
 // K3 with the exchange inside (CGX_COMM_P2P): iteration = K1 + this kernel, nothing else.
-// Workgroups 0..P-1 first push [Ap slice | folded p.Ap partial] into their peer's mailbox (same protocol as
-// k_mailbox_allgather); then EVERY workgroup waits (bounded) for all peers' flags and reads what it needs
-// straight from the mailbox slots with system-scope loads: the P scalars and, per thread, the one Ap element of
-// its row.  No copy-out pass, no kernel boundary between exchange and update.  All workgroups of the grid are
-// co-resident (n/256 <= a few hundred workgroups, nothing else runs on the device), so the pushers always make
-// progress while the others poll.
+// The (peer, chunk) pairs -- P x cpr of them, about as many as the kernel has workgroups -- are dealt over the grid: a
+// workgroup adds K1's column pieces for ONE chunk of kChunkRows rows, reduces the chunk's p.Ap partial, stores
+// [chunk of Ap | partial] into ONE peer's mailbox slot (its own included: own rows take the same road as everybody
+// else's) and raises that peer's flag word (me, chunk): one pass of independent loads, one 16-B store per thread, one fence,
+// one flag.  (Round 2 had P workgroups push a whole slice each: 8 dependent rounds of loads per pusher, and every
+// workgroup folded all of the rank's K1 partials -- 4096 with the columns split 8 ways: 13.4 us against 6.7 unsplit.)
+// Then EVERY workgroup waits (bounded) for all P x cpr flags in its own mailbox, lane f polling word f, and reads what
+// it needs straight from the slots with system-scope loads: the P x cpr partials, folded in one fixed order (bit-identical
+// on every rank, MPI_Allreduce cg.cc:106), and per thread the one Ap element of its row.  No copy-out pass, no kernel
+// boundary between exchange and update.  All workgroups must be co-resident (the host checks the occupancy): pushers
+// never wait before they have pushed, so every flag a workgroup polls is raised by a workgroup that is running.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_update_xr_p2p(int n, int rows, int row0, const double *__restrict__ p_new,
-                                                        SegView apv, int npart, MailboxView mv, int chan,
+                                                        SegView apv, int cpr, MailboxView mv, int chan,
                                                         unsigned long long epoch, double *__restrict__ x, SegView rv,
                                                         Scalars *sc, int parity_rs, long long timeout_ticks, int *err,
-                                                        const double *__restrict__ ap_parts, int split, long part_stride)
+                                                        const double *__restrict__ ap_src, int split, long part_stride)
 {
     __shared__ double lds[4];
-    __shared__ double s_sums[kMaxRanks];
     double *r = rv.base;
     const int tid = threadIdx.x, P = mv.nranks, me = mv.rank;
     const int done = sc->done;
@@ -1259,98 +1295,67 @@ __global__ __launch_bounds__(256) void k_update_xr_p2p(int n, int rows, int row0
     double r_i = 0.0, p_i = 0.0, x_i = 0.0;
     if (in) r_i = r[i];
     if (own) { p_i = p_new[i]; x_i = x[li]; }
-    const double *mine = apv.base + (long)me * apv.S;   // my segment: [Ap slice | npart partials]
-    double v = 0.0;
-    {
-        const double *tail = mine + apv.Sr;
-        int j = tid;
-        for (; j + 3 * 256 < npart; j += 4 * 256) {   // four independent loads in flight
-            const double a0 = tail[j], a1 = tail[j + 256], a2 = tail[j + 512], a3 = tail[j + 768];
-            v += (a0 + a1) + (a2 + a3);
-        }
-        for (; j < npart; j += 256) v += tail[j];
-    }
     // `done` is identical on every rank (r.r is bit-identical), so either all ranks exchange or none does
     if (__syncthreads_or(done | had_err)) return;
-    const double my_sum = block_sum<4>(v, lds);         // local half of MPI_Allreduce(p.Ap), cg.cc:105-106
 
     const int par = (int)(epoch & 1);
     const long slot = mv.slot_bytes[chan];
-    for (int peer = blockIdx.x; peer < P; peer += gridDim.x) {
-        if (peer == me) continue;
+    const int npairs = P * cpr;
+    for (int pr = blockIdx.x; pr < npairs; pr += gridDim.x) {        // uniform per workgroup
+        const int peer = pr / cpr, c = pr - peer * cpr;
+        const int row = (c * 256 + tid) * 2;                          // this thread's pair of rows of MY slice
+        const d2 a = chunk_pair(ap_src, split, part_stride, row, apv.Sr);
+        const double d = chunk_dot<4>(p_new + row0, a, row, rows, lds);   // local part of MPI_Allreduce(p.Ap), cg.cc:105-106
         double *out = reinterpret_cast<double *>(mv.base[peer] + mv.data_off[chan] + ((long)par * P + me) * slot);
-        const int pairs = apv.Sr >> 1;   // Sr is even
-        if (split > 1) {
-            for (int t = tid; t < pairs; t += 256) {   // K1 left the slice as `split` column pieces: add them, ascending
-                d2 a = *reinterpret_cast<const d2 *>(ap_parts + 2 * t);
-                for (int sp = 1; sp < split; ++sp) {
-                    const d2 b = *reinterpret_cast<const d2 *>(ap_parts + sp * part_stride + 2 * t);
-                    a.x += b.x;
-                    a.y += b.y;
-                }
-                *reinterpret_cast<d2 *>(out + 2 * t) = a;
-            }
-        } else
-        for (int t = tid; t < pairs; t += 256)
-            *reinterpret_cast<d2 *>(out + 2 * t) = *reinterpret_cast<const d2 *>(mine + 2 * t);
-        if (tid == 0) out[apv.Sr] = my_sum;
+        if (row < apv.Sr) *reinterpret_cast<d2 *>(out + row) = a;
+        if (tid == 0) out[apv.Sr + c] = d;
         __threadfence_system();   // release
         __syncthreads();
         if (tid == 0)
-            __hip_atomic_store(reinterpret_cast<unsigned long long *>(mv.base[peer] + ((long)chan * kMaxRanks + me) * kP2pFlagStride),
-                               epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(mv.base[peer] + mv.cflag_off) + (me * cpr + c), epoch,
+                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
-    // every workgroup: lane q waits for peer q's flag in MY mailbox (bounded by the 100 MHz wall clock)
+    // every workgroup: lane f waits for flag word f = (source rank, chunk) of MY mailbox (bounded by the 100 MHz wall clock)
     int ok = 1;
-    if (tid < P && tid != me) {
-        const unsigned long long *flag = reinterpret_cast<const unsigned long long *>(
-            mv.base[me] + ((long)chan * kMaxRanks + tid) * kP2pFlagStride);
-        const long long t0 = wall_clock64();
-        // relaxed polls (an acquire per poll would invalidate caches every time round: 2-3x slower per hop)
-        while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
-            __builtin_amdgcn_s_sleep(4);
-            if (wall_clock64() - t0 > timeout_ticks) {
-                ok = 0;
-                atomicExch(err, 1);
-                break;
+    {
+        const unsigned long long *flags = reinterpret_cast<const unsigned long long *>(mv.base[me] + mv.cflag_off);
+        for (int f = tid; f < npairs; f += 256) {
+            const long long t0 = wall_clock64();
+            // relaxed polls (an acquire per poll would invalidate caches every time round: 2-3x slower per hop)
+            while (__hip_atomic_load(flags + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+                __builtin_amdgcn_s_sleep(4);
+                if (wall_clock64() - t0 > timeout_ticks) {
+                    ok = 0;
+                    atomicExch(err, 1);
+                    break;
+                }
             }
         }
     }
-    // ONE system-scope acquire per workgroup, by the wave that polled, drained before the barrier releases the others
-    // (the consumer form of the guide: relaxed polls -> one acquire -> s_waitcnt vmcnt(0) -> barrier -> loads).  Every
-    // load of handed-off bytes below is a system-scope load as well, so nothing here rests on one mechanism alone
-    // when the peer's stores arrive over xGMI instead of from a process on the same GPU.
-    if (mv.acquire && tid < 64) {
+    // ONE system-scope acquire per polling wave, drained before the barrier releases the others (the consumer form of the
+    // guide: relaxed polls -> one acquire -> s_waitcnt vmcnt(0) -> barrier -> loads).  Every load of handed-off bytes
+    // below is a system-scope load as well, so nothing here rests on one mechanism alone when the peer's stores arrive
+    // over xGMI instead of from a process on the same GPU.
+    if (mv.acquire && (tid & ~63) < npairs) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     if (!__syncthreads_and(ok)) return;
     const unsigned long long *box = reinterpret_cast<const unsigned long long *>(mv.base[me] + mv.data_off[chan]);
     const long slot_w = slot / 8;
-    if (tid < P)
-        s_sums[tid] = (tid == me) ? my_sum
-                                  : __longlong_as_double((long long)__hip_atomic_load(
-                                        box + ((long)par * P + tid) * slot_w + apv.Sr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+    double cs = 0.0;
+    for (int f = tid; f < npairs; f += 256) {                        // all ranks' chunk partials, one fixed order
+        const int q = f / cpr, c = f - q * cpr;
+        cs += __longlong_as_double((long long)__hip_atomic_load(box + ((long)par * P + q) * slot_w + apv.Sr + c, __ATOMIC_RELAXED,
+                                                                  __HIP_MEMORY_SCOPE_SYSTEM));
+    }
     double ap_i = 0.0;
     if (in) {
         const int q = (P > 1) ? seg_owner(apv, i) : 0;
-        const int off = i - q * apv.n_loc;
-        double own_ap = 0.0;
-        if (q == me) {
-            if (split > 1) {
-                own_ap = ap_parts[off];
-                for (int sp = 1; sp < split; ++sp) own_ap += ap_parts[sp * part_stride + off];   // same order as the pushers
-            } else {
-                own_ap = mine[off];
-            }
-        }
-        ap_i = (q == me) ? own_ap
-                         : __longlong_as_double((long long)__hip_atomic_load(box + ((long)par * P + q) * slot_w + off,
-                                                                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        ap_i = __longlong_as_double((long long)__hip_atomic_load(box + ((long)par * P + q) * slot_w + (i - q * apv.n_loc),
+                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
     }
-    __syncthreads();
-    double conj = s_sums[0];
-    for (int q = 1; q < P; ++q) conj += s_sums[q];                   // rank order: bit-identical on every rank (cg.cc:106)
+    const double conj = block_sum<4>(cs, lds);                       // bit-identical on every rank (cg.cc:106)
     const double alpha = safeguarded_alpha(rsold, conj);             // cg.cc:107
     double rr = 0.0;
     if (in) {
@@ -1711,20 +1716,32 @@ hipError_t launch_dia_pack(const double *A, long lda, int n, int row0, int rows,
     return hipGetLastError();
 }
 
-hipError_t launch_update_xr_p2p(int n, int rows, int row0, const double *p_new, SegView apv, int npart,
+hipError_t launch_update_xr_p2p(int n, int rows, int row0, const double *p_new, SegView apv, int cpr,
                                 const MailboxView &mv, int chan, unsigned long long epoch, double *x, SegView rv, Scalars *sc,
-                                int parity, long long timeout_ticks, int *err, hipStream_t s, const double *ap_parts, int split,
+                                int parity, long long timeout_ticks, int *err, hipStream_t s, const double *ap_src, int split,
                                 long stride)
 {
-    hipLaunchKernelGGL(k_update_xr_p2p, dim3(update_xr_grid(n)), dim3(256), 0, s, n, rows, row0, p_new, apv, npart, mv, chan,
-                       epoch, x, rv, sc, parity, timeout_ticks, err, ap_parts, ap_parts ? split : 1, stride);
+    if (cpr != chunks_per_rank(apv.Sr) || (long)mv.nranks * cpr > kMaxChunkFlags) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_update_xr_p2p, dim3(update_xr_grid(n)), dim3(256), 0, s, n, rows, row0, p_new, apv, cpr, mv, chan,
+                       epoch, x, rv, sc, parity, timeout_ticks, err, ap_src, split, stride);
     return hipGetLastError();
 }
 
-hipError_t launch_combine_ap(const double *parts, int split, long stride, int count, double *dst, hipStream_t s)
+hipError_t update_xr_p2p_resident_limit(int device, int *workgroups)
 {
-    if (count <= 0) return hipSuccess;
-    hipLaunchKernelGGL(k_combine_ap, dim3(ceil_div(count, 512)), dim3(256), 0, s, parts, split, stride, count, dst);
+    int per_cu = 0, cus = 0;
+    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_update_xr_p2p, 256, 0);
+    if (e != hipSuccess) return e;
+    e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+    if (e != hipSuccess) return e;
+    *workgroups = per_cu * cus;
+    return hipSuccess;
+}
+
+hipError_t launch_prefold_ap(const double *parts, int split, long stride, int rows, int Sr, const double *p_loc, double *dst,
+                             double *tail, const Scalars *sc, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_prefold_ap, dim3(chunks_per_rank(Sr)), dim3(256), 0, s, parts, split, stride, rows, Sr, p_loc, dst, tail, sc);
     return hipGetLastError();
 }
 

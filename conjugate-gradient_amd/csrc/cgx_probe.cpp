@@ -137,6 +137,13 @@ cgx_status cgx_probe_set_fault_after(cgx_ctx *ctx, int calls)
     return CGX_OK;
 }
 
+cgx_status cgx_probe_set_resident_limit(cgx_ctx *ctx, int workgroups)
+{
+    if (!ctx) return CGX_ERR_BAD_ARG;
+    ctx->resident_limit = workgroups;
+    return CGX_OK;
+}
+
 // The DEVICE copy of b on local shard `local_shard` (n doubles): what init_source_term (cg.cc:218-234) left in HBM.
 cgx_status cgx_probe_get_source_term(cgx_ctx *ctx, int local_shard, double *b_out)
 {

@@ -213,13 +213,15 @@ cgx_status enqueue_iteration(cgx_ctx *ctx, int k)
         const unsigned long long epoch = ++ctx->p2p_epoch[1];
         HIP_TRY(ctx, cgx::launch_update_xr_p2p(ctx->n, s.rows, s.row0, s.p[(k + 1) & 1], s.apv, ctx->npart, ctx->mv, 1, epoch,
                                                s.x, s.rv, s.sc, k & 1, ctx->p2p_timeout_ticks, ctx->d_p2p_err, st,
-                                               s.plan.split > 1 ? s.ap_parts : nullptr, s.plan.split, ctx->seg_Sr));
+                                               s.plan.split > 1 ? s.ap_parts : s.Ap(), s.plan.split, ctx->seg_Sr));
         return CGX_OK;
     }
-    // every other consumer wants the Ap slice whole: add up the column pieces of a split K1 first
-    for (auto &s : ctx->shards)
-        if (s.plan.split > 1 && !ctx->banded)
-            HIP_TRY(ctx, cgx::launch_combine_ap(s.ap_parts, s.plan.split, ctx->seg_Sr, ctx->seg_Sr, s.Ap(), st));
+    // every other multi-rank consumer: K1's column pieces added up into the Ap slice of the segment, one p.Ap partial per
+    // chunk of the slice into its tail (k_prefold_ap) -- that is what travels
+    if (ctx->chunked)
+        for (auto &s : ctx->shards)
+            HIP_TRY(ctx, cgx::launch_prefold_ap(s.plan.split > 1 ? s.ap_parts : s.Ap(), s.plan.split, ctx->seg_Sr, s.rows, ctx->seg_Sr,
+                                                s.p[(k + 1) & 1] + s.row0, s.Ap(), s.tail(), s.sc, st));
     CGX_TRY(gather_segments(ctx, true));                                                             // cg.cc:106
     const bool folded = ctx->cfg.comm_mode == CGX_COMM_P2P;   // the exchange kernel already folded each rank's partials
     for (auto &s : ctx->shards)
@@ -309,10 +311,12 @@ cgx_status cgx_solve_steps(cgx_ctx *ctx, int nsteps, int *done_out)
     const double t0 = wall_now();
     // K1 statistics describe the most recent steps call (bench.py: the timed region, not the warmup)
     reset_gemv_stats(ctx);
+    bool window_open = false;   // the start marker of THIS call is on the stream (a stop marker is only paired with that)
     if (ctx->cfg.profile_gemv && nsteps > 0 && !ctx->done) {
         for (auto &e : ctx->steps_ev)
             if (!e) HIP_TRY(ctx, hipEventCreate(&e));
         HIP_TRY(ctx, hipEventRecord(ctx->steps_ev[0], ctx->stream));
+        window_open = true;
     }
     const int every = ctx->cfg.check_every;
     int slot = 0;
@@ -336,7 +340,7 @@ cgx_status cgx_solve_steps(cgx_ctx *ctx, int nsteps, int *done_out)
             if (ctx->h_flags[2 * slot]) stop = true;   // identical on every rank: rsnew is bit-identical (cg.cc:117-121)
         }
     }
-    if (ctx->cfg.profile_gemv && ctx->steps_ev[1] && nsteps > 0) {
+    if (window_open) {
         HIP_TRY(ctx, hipEventRecord(ctx->steps_ev[1], ctx->stream));
         ctx->steps_ev_pending = true;
     }

@@ -206,9 +206,13 @@ cgx_status  cgx_probe_time_gemv(cgx_ctx *ctx, int reps, double *ms_per_launch);
 cgx_status  cgx_probe_vector_ops(cgx_ctx *ctx, int n, double alpha, double beta, double *x, double *r,
                                  double *p, const double *Ap, double *rr);
 /* Error-path testing: after `calls` further HIP runtime calls of this context the next one is not made and reports a
- * failure instead (-1 = off; the same as CGX_FAULT_AFTER in the environment of cgx_create).  tools/leak_check.py and
- * tests/ use it to walk every early return of a probe, the self-test and the solve. */
+ * failure instead (-1 = off).  TEST-ONLY: tools/leak_check.py and tests/ use it to walk every early return of a probe,
+ * the self-test and the solve; nothing else (no environment variable) arms it. */
 cgx_status  cgx_probe_set_fault_after(cgx_ctx *ctx, int calls);
+/* Test hook for the co-residency guard of CGX_COMM_P2P's fused update kernel (its workgroups wait for each other inside the
+ * kernel, so its grid must not exceed what the device keeps resident: occupancy x CUs, queried from the runtime when a
+ * problem is set): workgroups > 0 replaces the queried bound for the problems set afterwards, 0 restores it. */
+cgx_status  cgx_probe_set_resident_limit(cgx_ctx *ctx, int workgroups);
 /* Copy the device-resident source term of local shard `local_shard` (n doubles, what cgx_init_source_term /
  * cgx_set_source_term left in HBM) back to the host: the bit-exact check of cg.cc:230-231. */
 cgx_status  cgx_probe_get_source_term(cgx_ctx *ctx, int local_shard, double *b_out);

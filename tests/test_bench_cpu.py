@@ -45,7 +45,8 @@ def test_self_launch_without_a_device_relays_rank0s_failure_line():
                        timeout=300, env=no_gpu_env())
     d = one_line(r.stdout)
     assert r.returncode != 0 and d["value"] is None and d["n_gpus"] == 4 and d["steps"] == 7 and d["warmup"] == 2
-    assert d["error"]["kind"] == "AssertionError" and "no CPU path" in d["error"]["message"]
+    # rank 0 either fails by itself (no device) or is stopped by the launcher because another rank failed first
+    assert (d["error"]["kind"] == "AssertionError" and "no CPU path" in d["error"]["message"]) or d["error"]["kind"] == "signal"
     assert "configs[3]" in d["config"]["workload"] and d["config"]["parallelism"] == "rowblock4"
     assert "starting 4 ranks" in r.stderr and "--nproc-per-node 4" in r.stderr
 

@@ -90,3 +90,30 @@ def test_p2p_wait_is_bounded(tmp_path):
     v = json.load(open(out))
     assert v["raised"] and v["status"] == 8, v
     assert 0.3 < v["seconds"] < 2.5, v          # ~0.4 s timeout once; later exchanges return at once
+
+
+def test_fused_update_refuses_a_grid_the_device_cannot_keep_resident(oracle):
+    """The workgroups of the fused update wait for each other inside the kernel, so its grid must fit the device at once:
+    the bound comes from the runtime (occupancy x CUs) when a problem is set; with the test hook it is forced below the
+    grid and the problem is refused with CGX_ERR_UNSUPPORTED instead of risking a dead wait."""
+    import numpy as np
+    import torch  # noqa: F401 -- before libcgx
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    n = 2048                                       # 8 workgroups of 256 rows
+    with pkg.CGSolver(comm_mode=pkg.COMM_P2P, nranks=1) as s:
+        s._set_resident_limit(7)
+        with pytest.raises(pkg.CgxError) as e:
+            s.generate_lap2d_matrix(n)
+        assert e.value.status == 7 and "must be resident at once" in str(e.value) and "8 workgroups" in str(e.value)
+        s._set_resident_limit(8)
+        s.generate_lap2d_matrix(n)                 # exactly fits
+        s._set_resident_limit(0)                   # the runtime's own bound: thousands
+        s.generate_lap2d_matrix(n + 2)
+        s.set_max_iter(60)
+        s.init_source_term(1.0 / (n + 2))
+        x = np.zeros(n + 2)
+        r = s.solve(x)
+    xo, ro = oracle.solve_lap2d(n + 2, 60, 1e-10, 1)
+    assert r["iterations"] == 60 and np.linalg.norm(x - xo) <= 1e-12 * np.linalg.norm(xo)

@@ -235,7 +235,8 @@ def test_fixed_iteration_solve_matches_oracle(gpu_pkg, oracle, n, max_iter, mode
     assert rel(r["rel_residual"], ro["rel_residual"]) < tol
 
 
-@pytest.mark.parametrize("n,max_iter,p,variant", [(3, 2, 4, 0), (5, 3, 8, 0), (7, 4, 7, 0), (9, 5, 4, 20441), (2, 1, 3, 0)])
+@pytest.mark.parametrize("n,max_iter,p,variant", [(3, 2, 4, 0), (5, 3, 8, 0), (7, 4, 7, 0), (9, 5, 4, 20441), (2, 1, 3, 0),
+                                                  (3, 2, 4, 10442), (5, 3, 8, 10444), (9, 5, 3, 10822), (2, 1, 3, 10825)])   # one-round forms on empty shards
 def test_fewer_rows_than_ranks(gpu_pkg, oracle, n, max_iter, p, variant):
     """N < P or N ~ P: shards without rows (floor(N/P) = 0, cg.cc:255) still take part in every exchange.  tol = 0
     on both sides so that the comparison does not depend on which side's rounding converges first."""

@@ -25,7 +25,7 @@ assert abs(lows[-1] - lows[0]) < 64, lows
 print("no leak: free memory stable within %.1f MiB" % abs(lows[-1] - lows[0]))
 
 # ---- forced-failure leg: every HIP call of a probe / self-test / solve is made to fail in turn
-# (CGX_FAULT_AFTER, cgx_internal.h) and the device's free memory must come back each time.
+# (cgx_probe_set_fault_after, cgx_internal.h) and the device's free memory must come back each time.
 def forced_failures(name, build, act, max_calls):
     base, hit = None, 0
     for k in range(max_calls):
