@@ -146,7 +146,11 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
         return ctx->banded ? cgx::plan_dia(rows, variant) : cgx::plan_gemv(variant, rows, ctx->n, ctx->lda, allow_split);
     };
     int grid_max = 1;
-    for (int q = 0; q < ctx->nranks; ++q) grid_max = std::max(grid_max, plan_for(ctx->num_rows[q]).grid);
+    for (int q = 0; q < ctx->nranks; ++q) {
+        const cgx::GemvPlan pl = plan_for(ctx->num_rows[q]);
+        grid_max = std::max(grid_max, pl.grid);
+        if (pl.split > 1) ctx->chunked = true;   // an explicit column-split shape on one GPU: somebody has to add the pieces
+    }
     const int cpr = cgx::chunks_per_rank(ctx->seg_Sr);
     ctx->npart = ctx->chunked ? cpr : grid_max;
     if (fused_p2p) {

@@ -624,27 +624,40 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_ldsp(const double *__restri
 // folded by anybody on a multi-GPU run.  Used by k_prefold_ap (RCCL, separate mailbox exchange, loopback) and by the
 // pushers of k_update_xr_p2p (fused exchange): the same code, the same bits on every transport.
 // ------------------------------------------------------------------------------------------------
+// Branch-free: every load is unconditional (clamped index, value dropped by a select), so that all of them -- up to
+// kMaxSplit pieces and the two elements of p -- are in flight together; loads behind a branch or in a loop of unknown
+// length are waited for one by one (seen in the ISA: s_waitcnt vmcnt(0) after each piece).
+constexpr int kMaxSplit = 8;
 __device__ __forceinline__ d2 chunk_pair(const double *__restrict__ parts, int split, long stride, int row, int Sr)
 {
-    d2 a{0.0, 0.0};
-    if (row < Sr) {                                                  // Sr is even, slices are 16-B aligned
-        a = *reinterpret_cast<const d2 *>(parts + row);
-        for (int sp = 1; sp < split; ++sp) {
-            const d2 b = *reinterpret_cast<const d2 *>(parts + sp * stride + row);
-            a.x += b.x;
-            a.y += b.y;
-        }
+    const int rc = row < Sr ? row : Sr - 2;                           // Sr is even and >= 2, slices are 16-B aligned
+    d2 v[kMaxSplit];
+#pragma unroll
+    for (int sp = 0; sp < kMaxSplit; ++sp)
+        v[sp] = *reinterpret_cast<const d2 *>(parts + (sp < split ? sp : split - 1) * stride + rc);
+    d2 a = v[0];
+#pragma unroll
+    for (int sp = 1; sp < kMaxSplit; ++sp) {                          // ascending piece order
+        a.x = sp < split ? a.x + v[sp].x : a.x;
+        a.y = sp < split ? a.y + v[sp].y : a.y;
     }
+    if (row >= Sr) a = d2{0.0, 0.0};
     return a;
 }
 
-template <int WAVES>
-__device__ __forceinline__ double chunk_dot(const double *__restrict__ p_loc /* p_new + row0 */, d2 a, int row, int rows, double *lds)
+// the pair's two elements of p_sub (p_loc = p_new + row0; row0 may be odd: 8-B loads), 0 behind the last row
+__device__ __forceinline__ d2 chunk_p(const double *__restrict__ p_loc, int row, int rows)
 {
-    double d = 0.0;
-    if (row < rows) d = p_loc[row] * a.x;                            // row0 may be odd: 8-B loads
-    if (row + 1 < rows) d = fma(p_loc[row + 1], a.y, d);
-    return block_sum<WAVES>(d, lds);
+    const int last = rows > 0 ? rows - 1 : 0;                         // rows == 0: p_loc[0] is still inside p (zero pad)
+    const double p0 = p_loc[row < rows ? row : last];
+    const double p1 = p_loc[row + 1 < rows ? row + 1 : last];
+    return d2{row < rows ? p0 : 0.0, row + 1 < rows ? p1 : 0.0};
+}
+
+template <int WAVES>
+__device__ __forceinline__ double chunk_dot(d2 p, d2 a, double *lds)
+{
+    return block_sum<WAVES>(fma(p.y, a.y, p.x * a.x), lds);
 }
 
 // One workgroup per chunk, in front of the exchange: dst = the Ap slice of this rank's segment, tail = its chunk partials.
@@ -653,12 +666,16 @@ __global__ __launch_bounds__(256) void k_prefold_ap(const double *__restrict__ p
                                                      double *__restrict__ tail, const Scalars *sc)
 {
     __shared__ double lds[4];
-    if (sc->done) return;                                            // converged earlier (uniform): K3 will not look either
+    // every load of the kernel is issued before the first wait: one memory round trip, not a chain of them
+    const int done = sc->done;
     const int row = ((int)blockIdx.x * 256 + (int)threadIdx.x) * 2;
+    const d2 p = chunk_p(p_loc, row, rows);
     const d2 a = chunk_pair(parts, split, stride, row, Sr);
-    if (split > 1 && row < Sr) *reinterpret_cast<d2 *>(dst + row) = a;
-    const double d = chunk_dot<4>(p_loc, a, row, rows, lds);
-    if (threadIdx.x == 0) tail[blockIdx.x] = d;
+    // converged earlier (uniform): nothing is stored -- as a predicate on the stores, not as an early return, which the
+    // compiler turns into "wait for the flag, then start loading" (seen in the ISA)
+    if (!done && split > 1 && row < Sr) *reinterpret_cast<d2 *>(dst + row) = a;
+    const double d = chunk_dot<4>(p, a, lds);
+    if (!done && threadIdx.x == 0) tail[blockIdx.x] = d;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -685,15 +702,28 @@ __global__ __launch_bounds__(256) void k_update_xr(int n, int rows, int row0, co
     if (own) { p_i = p_new[i]; x_i = x[li]; }
     // p.Ap = sum of every K1 workgroup partial of every rank (cblas_ddot + MPI_Allreduce, cg.cc:105-106), folded
     // in one fixed order by every workgroup of every rank: bit-identical everywhere.
+    // One flat index over (rank, partial): with a few partials per rank (the chunk partials of a multi-GPU run: n/512 in
+    // all) every thread has at most one or two loads, all in flight together -- a loop over the ranks with one load each was
+    // a chain of P dependent round trips (5.9 us at P = 8 against 4.8 at P = 2 and 4, round 3).
     double cs = 0.0;
-    for (int q = 0; q < apv.nranks; ++q) {
-        const double *tail = apv.base + (long)q * apv.S + apv.Sr + tail_off;
-        int j = threadIdx.x;
-        for (; j + 3 * 256 < tail_count; j += 4 * 256) {   // four independent loads in flight
-            const double a0 = tail[j], a1 = tail[j + 256], a2 = tail[j + 512], a3 = tail[j + 768];
-            cs += (a0 + a1) + (a2 + a3);
+    {
+        const int total = apv.nranks * tail_count;
+        const double *tails = apv.base + apv.Sr + tail_off;
+        auto at = [&](int f) {
+            if (apv.nranks == 1) return tails[f];
+            const int q = f / tail_count;
+            return tails[(long)q * apv.S + (f - q * tail_count)];
+        };
+        for (int f = threadIdx.x; f < total; f += 4 * 256) {   // four independent loads in flight (clamped, not branched around)
+            double a[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int g = f + u * 256;
+                const double val = at(g < total ? g : total - 1);
+                a[u] = g < total ? val : 0.0;
+            }
+            cs += (a[0] + a[1]) + (a[2] + a[3]);
         }
-        for (; j < tail_count; j += 256) cs += tail[j];
     }
     if (done) return;   // converged earlier (uniform over the grid): nothing is written
     const double conj = block_sum<4>(cs, lds);
@@ -1185,7 +1215,7 @@ __global__ __launch_bounds__(256) void k_mailbox_allgather(MailboxView mv, int c
     const int tid = threadIdx.x;
     // an earlier wait expired: do not wait again, let the host see it.  Decided per workgroup (another workgroup may
     // raise the word while this one starts), so that no thread is left alone at a barrier.
-    if (__syncthreads_or(*reinterpret_cast<volatile int *>(err))) return;
+    if (__syncthreads_or(__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return;
     __shared__ double lds[4];
     double tail_sum = 0.0;
     if (tail_n > 0) {
@@ -1287,7 +1317,9 @@ __global__ __launch_bounds__(256) void k_update_xr_p2p(int n, int rows, int row0
     double *r = rv.base;
     const int tid = threadIdx.x, P = mv.nranks, me = mv.rank;
     const int done = sc->done;
-    const int had_err = *reinterpret_cast<volatile int *>(err);
+    // (an atomic load, not a volatile one: the compiler waits for a volatile load on the spot -- a whole memory round trip
+    // at the top of the kernel with nothing else in flight, seen in the ISA)
+    const int had_err = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const double rsold = sc->rs[parity_rs];
     const int i = blockIdx.x * 256 + tid;   // global row
     const int li = i - row0;
@@ -1295,25 +1327,41 @@ __global__ __launch_bounds__(256) void k_update_xr_p2p(int n, int rows, int row0
     double r_i = 0.0, p_i = 0.0, x_i = 0.0;
     if (in) r_i = r[i];
     if (own) { p_i = p_new[i]; x_i = x[li]; }
-    // `done` is identical on every rank (r.r is bit-identical), so either all ranks exchange or none does
-    if (__syncthreads_or(done | had_err)) return;
-
     const int par = (int)(epoch & 1);
     const long slot = mv.slot_bytes[chan];
     const int npairs = P * cpr;
-    for (int pr = blockIdx.x; pr < npairs; pr += gridDim.x) {        // uniform per workgroup
-        const int peer = pr / cpr, c = pr - peer * cpr;
-        const int row = (c * 256 + tid) * 2;                          // this thread's pair of rows of MY slice
-        const d2 a = chunk_pair(ap_src, split, part_stride, row, apv.Sr);
-        const double d = chunk_dot<4>(p_new + row0, a, row, rows, lds);   // local part of MPI_Allreduce(p.Ap), cg.cc:105-106
+    // the first (peer, chunk) pair of this workgroup: its loads go out with the ones above, ahead of the first wait
+    int pr = blockIdx.x;
+    int peer = 0, c = 0, row = 0;
+    d2 a{0.0, 0.0}, pp{0.0, 0.0};
+    if (pr < npairs) {                                               // uniform per workgroup
+        peer = pr / cpr;
+        c = pr - peer * cpr;
+        row = (c * 256 + tid) * 2;                                   // this thread's pair of rows of MY slice
+        pp = chunk_p(p_new + row0, row, rows);
+        a = chunk_pair(ap_src, split, part_stride, row, apv.Sr);
+    }
+    // `done` is identical on every rank (r.r is bit-identical), so either all ranks exchange or none does
+    if (__syncthreads_or(done | had_err)) return;
+    while (pr < npairs) {
+        const double d = chunk_dot<4>(pp, a, lds);                    // local part of MPI_Allreduce(p.Ap), cg.cc:105-106
         double *out = reinterpret_cast<double *>(mv.base[peer] + mv.data_off[chan] + ((long)par * P + me) * slot);
         if (row < apv.Sr) *reinterpret_cast<d2 *>(out + row) = a;
         if (tid == 0) out[apv.Sr + c] = d;
-        __threadfence_system();   // release
+        // Release: the barrier orders every wave's stores before lane 0's system-scope release store of the flag (workgroup
+        // release + barrier, then one system release: cumulative), instead of a system-scope fence in all four waves.
         __syncthreads();
         if (tid == 0)
             __hip_atomic_store(reinterpret_cast<unsigned long long *>(mv.base[peer] + mv.cflag_off) + (me * cpr + c), epoch,
                                __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        pr += gridDim.x;
+        if (pr < npairs) {
+            peer = pr / cpr;
+            c = pr - peer * cpr;
+            row = (c * 256 + tid) * 2;
+            pp = chunk_p(p_new + row0, row, rows);
+            a = chunk_pair(ap_src, split, part_stride, row, apv.Sr);
+        }
     }
     // every workgroup: lane f waits for flag word f = (source rank, chunk) of MY mailbox (bounded by the 100 MHz wall clock)
     int ok = 1;
@@ -1415,11 +1463,12 @@ GemvPlan plan_gemv(int variant, int rows, int n, long lda, bool allow_split)
         //    on 8192 x 32768 (profiles/r02_k1_shards/); up to 16384 rows the one-round form of (8,2): 605.2 against 608.5.
         if (rows >= 2048 && block_bytes > 256.0 * 1024 * 1024) {
             if (rows <= 16384 && allow_split) {
-                // the consumer adds the column pieces itself (fused P2P update): (8,2) one-round form, pieces tied to the
-                // XCDs, as many as keep the p.Ap partials of the rank at <= 4096 (what K3 folds on one GPU today)
+                // multi-rank run: whoever consumes Ap adds the column pieces itself (k_prefold_ap or the fused P2P update) and
+                // nobody folds K1's own partials, so their number does not matter: (8,2) one-round form, 8 pieces = one per
+                // XCD.  Round 3, rocprofv3, loopback shards of N=32768: 153.3 / 302.8 / 603.0 us at P = 8 / 4 / 2 against
+                // 156.1 / 307.2 / 604.9 unsplit; 4 pieces at P=4: 304.1, 2 or 4 at P=2: 604.0 / 605.8.
                 pl.R = 8; pl.U = 2; pl.light = 1;
-                const int groups = (rows + 7) / 8;
-                pl.split = groups <= 512 ? 8 : (groups <= 1024 ? 4 : (groups <= 2048 ? 2 : 1));
+                pl.split = 8;
             }
             else if (rows <= 8192) { pl.R = 4; pl.U = 4; pl.light = 1; }
             else if (rows <= 16384) { pl.R = 8; pl.U = 2; pl.light = 1; }
