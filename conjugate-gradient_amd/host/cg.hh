@@ -18,25 +18,27 @@ public:
     CGSolver();
     /// explicit placement: comm mode, rank/nranks (what MPI_Comm_rank/size gave the reference), device
     explicit CGSolver(const cgx_config &cfg);
-    ~CGSolver();
+    virtual ~CGSolver();
     CGSolver(const CGSolver &) = delete;
     CGSolver &operator=(const CGSolver &) = delete;
 
+    // The members the reference declares virtual (code/MPI/cg.hh:17-32) are virtual here too: a drop-in header must not
+    // narrow the interface for a caller that derives from CGSolver.
     /// read matrix from .mtx file (code/MPI/cg.hh:17; sizes are set as in code/CUDA/cg.cu:317-319)
-    void read_matrix(const std::string &filename);
+    virtual void read_matrix(const std::string &filename);
     /// initialize source term (cg.hh:20)
     void init_source_term(double h);
     /// partition matrix (cg.hh:23)
-    void partition_matrix(int N, int psize, int start_rows[], int num_rows[]);
+    virtual void partition_matrix(int N, int psize, int start_rows[], int num_rows[]);
     /// generate the synthetic matrix for the scaling experiments (cg.hh:26)
-    void generate_lap2d_matrix(int size);
+    virtual void generate_lap2d_matrix(int size);
     /// conjugate gradient, MPI-form signature (cg.hh:29): x = initial guess in, solution out
-    void solve(std::vector<double> &x);
+    virtual void solve(std::vector<double> &x);
     /// CUDA-form signature (code/CUDA/cg.hh:29).  NUM_THREADS / BLOCK_WIDTH / T tuned the reference's
     /// own kernels and have no counterpart here: accepted and ignored.  x is zeroed first (cg.cu:217).
     void solve(double *x, int NUM_THREADS, int BLOCK_WIDTH, bool T);
     /// fix maximum number of iterations (cg.hh:32)
-    void set_max_iter(int maxIter);
+    virtual void set_max_iter(int maxIter);
     int m() const;
     int n() const;
     /// residual tolerance (cg.hh:39)

@@ -11,17 +11,22 @@
 // `--loopback P` runs P logical row blocks on one GPU (CI stand-in for a multi-GPU node).
 // `--banded` (NOT a reference mode) holds the matrix as its non-zero diagonals: same recurrence and output, a
 // banded mat-vec instead of the dense GEMV; refused if the matrix has more than 64 diagonals.
+#include <signal.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
 #include <chrono>
+#include <condition_variable>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <functional>
 #include <iostream>
 #include <memory>
+#include <mutex>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "cg.hh"
@@ -41,6 +46,75 @@ bool parse_int(const std::string &s, int *out)
     return true;
 }
 
+// ---- bounded wire-up ---------------------------------------------------------------------------------------
+// Every stage of the multi-GPU wire-up that can block on a peer (the device probe's agreement, the mailbox handle
+// exchange, cgx_p2p_import, the self-test, ncclCommInitRank) runs under a deadline.  MPI_Init either returns or the job
+// is killed by the scheduler (code/MPI/cg_main.cc:15-20 under srun); here a stage that does not come back makes the rank
+// print one line and leave with exit code 1 -- rank 0 first ends and reaps the other ranks -- so that a script like
+// experiments/cg_mi355x.run can never hang on a dead peer.  Nothing is retried or restarted in place.
+class StageWatchdog {
+public:
+    StageWatchdog(int rank, const std::vector<pid_t> *kids) : rank_(rank), kids_(kids), thread_([this] { run(); }) {}
+    ~StageWatchdog()
+    {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        thread_.join();
+    }
+    void arm(const std::string &stage, double seconds)
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        stage_ = stage;
+        seconds_ = seconds;
+        deadline_ = std::chrono::steady_clock::now() + std::chrono::duration_cast<std::chrono::steady_clock::duration>(
+                                                           std::chrono::duration<double>(seconds));
+        armed_ = true;
+        cv_.notify_all();
+    }
+    void disarm()
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        armed_ = false;
+        cv_.notify_all();
+    }
+
+private:
+    void run()
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        while (!quit_) {
+            if (!armed_) {
+                cv_.wait(lk);
+                continue;
+            }
+            if (cv_.wait_until(lk, deadline_) == std::cv_status::timeout && armed_ && !quit_ &&
+                std::chrono::steady_clock::now() >= deadline_) {
+                std::cerr << "cgsolver (rank " << rank_ << "): wire-up stage '" << stage_ << "' did not finish within " << seconds_
+                          << " s; giving up" << std::endl;
+                if (kids_)   // rank 0: end the other ranks and reap them, so that nothing of the job is left behind
+                    for (pid_t k : *kids_) {
+                        kill(k, SIGKILL);
+                        int st = 0;
+                        waitpid(k, &st, 0);
+                    }
+                _exit(1);
+            }
+        }
+    }
+    const int rank_;
+    const std::vector<pid_t> *kids_;
+    std::mutex m_;
+    std::condition_variable cv_;
+    bool armed_ = false, quit_ = false;
+    std::string stage_;
+    double seconds_ = 0;
+    std::chrono::steady_clock::time_point deadline_;
+    std::thread thread_;
+};
+
 int usage(const char *prog)
 {
     std::cerr << "Usage: " << prog << " N OUTFILE [MAXITER]            (generated matrix of size N)\n"
@@ -48,6 +122,8 @@ int usage(const char *prog)
               << "       " << prog << " FILE.mtx OUTFILE [MAXITER]       (matrix file, MPI-form output)\n"
               << "options: --gpus P (or CG_NGPU=P)  one process per MI355X\n"
               << "         --transport auto|p2p|rccl  exchange: direct xGMI mailboxes, RCCL, or p2p with RCCL fallback\n"
+              << "         --wireup-timeout S       seconds any one stage of the multi-GPU wire-up may take (default 120, or\n"
+              << "                                  CG_WIREUP_TIMEOUT); a stage that does not come back ends the job with exit code 1\n"
               << "         --loopback P             P logical row blocks on one GPU\n"
               << "         --banded                 opt-in, not in the reference: store the non-zero diagonals only (<= 64)\n"
               << "         --stats                  also print iterations/s and K1 GB/s on stderr (event-times every K1:\n"
@@ -67,6 +143,8 @@ int main(int argc, char **argv)
     int ngpu = 1, loopback = 0;
     bool stats = false, same_device = false, banded = false;
     std::string transport = "auto";
+    double wireup_timeout = 120.0;
+    if (const char *e = getenv("CG_WIREUP_TIMEOUT")) wireup_timeout = atof(e);
     if (const char *e = getenv("CG_NGPU")) ngpu = atoi(e);
     for (int i = 1; i < argc; ++i) {
         std::string a(argv[i]);
@@ -75,6 +153,7 @@ int main(int argc, char **argv)
         else if (a == "--stats") stats = true;
         else if (a == "--banded") banded = true;
         else if (a == "--transport" && i + 1 < argc) transport = argv[++i];
+        else if (a == "--wireup-timeout" && i + 1 < argc) wireup_timeout = atof(argv[++i]);
         else if (a == "--same-device") same_device = true;   // rehearsal: every rank on device 0 (p2p only)
         else if (a == "--cpu") {
             // SURVEY.md section 8(b) named a --cpu switch for the CPU restatement.  The product has no CPU path by design
@@ -202,7 +281,16 @@ int main(int argc, char **argv)
             cfg.nranks = ngpu;
             cfg.rank = rank;
             cfg.device = same_device ? 0 : rank;
-            {
+            // one deadline per stage; the watchdog thread starts here, i.e. after the fork (threads do not survive one)
+            StageWatchdog dog(rank, rank == 0 ? &kids : nullptr);
+            const char *hang = getenv("CG_TEST_HANG_STAGE");   // test hook: "<stage>:<rank>" never comes back (tests/test_cli_wireup.py)
+            auto stage = [&](const std::string &name, const std::function<void()> &body) {
+                dog.arm(name, wireup_timeout);
+                if (hang && std::string(hang) == name + ":" + std::to_string(rank)) pause();
+                body();
+                dog.disarm();
+            };
+            stage("device probe", [&] {
                 // every rank must own a usable GPU before any collective wire-up is attempted (a rank that cannot
                 // create a context would otherwise leave the others blocked in ncclCommInitRank)
                 cgx_config probe;
@@ -213,28 +301,36 @@ int main(int argc, char **argv)
                 if (!dev_ok) std::cerr << "cgsolver (rank " << rank << "): " << cgx_last_error(nullptr) << std::endl;
                 cgx_destroy(pc);
                 if (!all_min(dev_ok)) throw std::runtime_error("--gpus " + std::to_string(ngpu) + ": not every rank has a usable MI355X");
-            }
+            });
             bool have = false;
             if (transport != "rccl") {
                 // direct-xGMI mailboxes: create, exchange IPC handles, self-test; all ranks agree on the outcome
                 cfg.comm_mode = CGX_COMM_P2P;
                 int ok = 1;
-                unsigned char handle[CGX_IPC_HANDLE_BYTES] = {0};
-                try {
-                    holder.reset(new CGSolver(cfg));
-                    if (cgx_p2p_export(holder->context(), handle) != CGX_OK) ok = 0;
-                } catch (const std::exception &e) {
-                    std::cerr << "cgsolver (rank " << rank << "): p2p unavailable: " << e.what() << std::endl;
-                    ok = 0;
-                }
-                std::vector<unsigned char> all = allgather_bytes(handle, CGX_IPC_HANDLE_BYTES);
-                if (all_min(ok)) {
-                    int st_ok = 0;
-                    if (cgx_p2p_import(holder->context(), all.data()) != CGX_OK) ok = 0;
-                    if (all_min(ok)) {
-                        if (cgx_p2p_selftest(holder->context(), 32, &st_ok) != CGX_OK) st_ok = 0;
-                        have = all_min(st_ok) != 0;
+                std::vector<unsigned char> all;
+                stage("mailbox allocation", [&] {
+                    unsigned char handle[CGX_IPC_HANDLE_BYTES] = {0};
+                    try {
+                        holder.reset(new CGSolver(cfg));
+                        if (cgx_p2p_export(holder->context(), handle) != CGX_OK) ok = 0;
+                    } catch (const std::exception &e) {
+                        std::cerr << "cgsolver (rank " << rank << "): p2p unavailable: " << e.what() << std::endl;
+                        ok = 0;
                     }
+                    all = allgather_bytes(handle, CGX_IPC_HANDLE_BYTES);
+                    ok = all_min(ok);
+                });
+                if (ok) {
+                    stage("opening the peers' mailboxes", [&] {
+                        if (cgx_p2p_import(holder->context(), all.data()) != CGX_OK) ok = 0;
+                        ok = all_min(ok);
+                    });
+                    if (ok)
+                        stage("mailbox self-test", [&] {
+                            int st_ok = 0;
+                            if (cgx_p2p_selftest(holder->context(), 32, &st_ok) != CGX_OK) st_ok = 0;
+                            have = all_min(st_ok) != 0;
+                        });
                 }
                 if (!have) {
                     holder.reset();
@@ -244,12 +340,14 @@ int main(int argc, char **argv)
             }
             if (!have) {
                 cfg.comm_mode = CGX_COMM_RCCL;
-                unsigned char uid[CGX_UNIQUE_ID_BYTES] = {0};
-                if (rank == 0 && cgx_comm_unique_id(uid) != CGX_OK)
-                    throw std::runtime_error(std::string("cgx_comm_unique_id: ") + cgx_last_error(nullptr));
-                std::vector<unsigned char> all = allgather_bytes(uid, CGX_UNIQUE_ID_BYTES);
-                memcpy(cfg.unique_id, all.data(), CGX_UNIQUE_ID_BYTES);   // rank 0's id
-                holder.reset(new CGSolver(cfg));
+                stage("ncclCommInitRank", [&] {
+                    unsigned char uid[CGX_UNIQUE_ID_BYTES] = {0};
+                    if (rank == 0 && cgx_comm_unique_id(uid) != CGX_OK)
+                        throw std::runtime_error(std::string("cgx_comm_unique_id: ") + cgx_last_error(nullptr));
+                    std::vector<unsigned char> all = allgather_bytes(uid, CGX_UNIQUE_ID_BYTES);
+                    memcpy(cfg.unique_id, all.data(), CGX_UNIQUE_ID_BYTES);   // rank 0's id
+                    holder.reset(new CGSolver(cfg));
+                });
             }
         } else {
             if (loopback > 1) {
@@ -298,7 +396,9 @@ int main(int argc, char **argv)
         rc = 1;
     }
 
+    // rank 0 reaps the other ranks; if it failed itself they may be blocked on it (a pipe read, a collective): end them
     for (pid_t k : kids) {
+        if (rc != 0) kill(k, SIGTERM);
         int st = 0;
         waitpid(k, &st, 0);
         if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) rc = 1;

@@ -133,3 +133,44 @@ int main(void) {
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert r.stdout.strip() in ("gpu", "no usable GPU (libcgx has no CPU fallback)")
+
+
+def test_mirror_class_keeps_the_reference_members_virtual(pkg, tmp_path):
+    """code/MPI/cg.hh:17-32 declares read_matrix, partition_matrix, generate_lap2d_matrix, solve and set_max_iter virtual: a
+    caller that derives from CGSolver and overrides them must keep working with the drop-in header (host/cg.hh).  Compiled
+    with the reference's own warning flags (code/MPI/Makefile:3); the override is reached through a base reference."""
+    src = tmp_path / "derived.cc"
+    src.write_text(r'''
+#include "cg.hh"
+#include <cstdio>
+#include <type_traits>
+struct Mine : CGSolver {
+    int calls = 0;
+    void read_matrix(const std::string &) override { ++calls; }
+    void partition_matrix(int, int, int[], int[]) override { ++calls; }
+    void generate_lap2d_matrix(int) override { ++calls; }
+    void solve(std::vector<double> &) override { ++calls; }
+    void set_max_iter(int) override { ++calls; }
+};
+static_assert(std::has_virtual_destructor<CGSolver>::value, "a polymorphic base needs a virtual destructor");
+int through_base(CGSolver &s)
+{
+    std::vector<double> x;
+    int a[1], b[1];
+    s.read_matrix("f");
+    s.partition_matrix(1, 1, a, b);
+    s.generate_lap2d_matrix(4);
+    s.solve(x);
+    s.set_max_iter(3);
+    return 0;
+}
+int main() { std::printf("%d\n", (int)std::is_polymorphic<CGSolver>::value); return 0; }
+''')
+    exe = tmp_path / "derived"
+    pkgdir = os.path.dirname(pkg.cgx.LIB_PATH)
+    r = subprocess.run(["g++", "-std=c++11", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"),
+                        "-I", os.path.join(pkgdir, "host"), str(src), os.path.join(pkgdir, "host", "cg.cc"), "-o", str(exe),
+                        "-L", pkgdir, "-lcgx", "-Wl,-rpath," + pkgdir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0 and r.stdout.strip() == "1"
