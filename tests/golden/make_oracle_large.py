@@ -5,6 +5,8 @@ Usage (dev container, ~10 min single core, up to 17 GB RAM):
       n:max_iter:psize        dense restatement (oracle_solve_lap2d: the n x n block is held in RAM)
       bn:max_iter:psize       the on-the-fly twin (oracle_solve_lap2d_banded: same solve_blocks, the five entries of a
                               row come from the generator's rule, cg.cc:181-185); seconds instead of minutes, any n
+      cn:psize                dense restatement run to CONVERGENCE (max_iter = n as cg.cc:172, tol 1e-10): BASELINE.json
+                              configs[1] is c10000:1 (~40 s, 800 MB); 20 sampled entries of x
       mtx                     tests/golden/lap2D_5pt_n100.mtx, init_source_term(1/n), run to convergence (tol 1e-10)
 Writes/updates tests/golden/oracle_large.json.  The tests compare these oracle outputs with the
 reference outputs in reference_probe.json (pinning the oracle) and the GPU path with both.
@@ -18,7 +20,7 @@ sys.path.insert(0, os.path.join(HERE, "..", ".."))
 from oracle import oracle as O  # noqa: E402
 
 OUT = os.path.join(HERE, "oracle_large.json")
-DEFAULT = ["16384:200:1", "23170:200:2", "32768:500:1", "b32768:200:4", "b46340:200:8", "mtx"]
+DEFAULT = ["16384:200:1", "23170:200:2", "32768:500:1", "b32768:200:4", "b46340:200:8", "mtx", "c10000:1"]
 
 
 def sample_indices(n, extra=()):
@@ -44,6 +46,16 @@ def main(argv):
                    "rel_residual": r["rel_residual"], "x_samples": {str(i): float(x[i]) for i in idx},
                    "seconds_loop": r["seconds_loop"]}
             data["mtx"] = [row]
+            json.dump(data, open(OUT, "w"), indent=1)
+            print(json.dumps(row), flush=True)
+            continue
+        if c.startswith("c"):
+            n, ps = (int(v) for v in c[1:].split(":"))
+            x, r = O.solve_lap2d(n, n, 1e-10, ps)                      # m_maxIter = size, cg.cc:172; cg_main.cc:31-55
+            row = {"n": n, "psize": ps, "k": r["iterations"], "converged": bool(r["converged"]), "residual": r["residual_prev"],
+                   "residual_last": r["residual_last"], "x_norm": r["x_norm"], "rel_residual": r["rel_residual"],
+                   "x_samples": {str(i): float(x[i]) for i in sample_indices(n)}, "seconds_loop": r["seconds_loop"]}
+            data["converged"] = [q for q in data.get("converged", []) if not (q["n"] == n and q["psize"] == ps)] + [row]
             json.dump(data, open(OUT, "w"), indent=1)
             print(json.dumps(row), flush=True)
             continue

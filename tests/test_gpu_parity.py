@@ -541,6 +541,22 @@ def test_config2_n10000_converges_like_reference(gpu_pkg, reference_probe):
     assert rel(r["x_norm"], row["x_norm"]) < 1e-6 and r["rel_residual"] <= 3e-11
 
 
+@pytest.mark.parametrize("mode,p", [(None, 1), (1, 4)])
+def test_config2_n10000_matches_the_oracle_run_to_convergence(gpu_pkg, oracle_large, mode, p):
+    """configs[1] against the committed oracle run to convergence (tests/golden/oracle_large.json "converged", 20 sampled
+    entries of x at full precision; cg_main.cc:31-55): both stop below 1e-10 at their own k, the solutions agree far below
+    the 1e-10 bar -- on one GPU and as four row blocks."""
+    row = [q for q in oracle_large["converged"] if q["n"] == 10000][0]
+    with make(gpu_pkg, 10000, mode, p) as s:
+        x = np.zeros(10000)
+        r = s.solve(x)
+    assert r["converged"] and r["residual_last"] < 1e-10 and abs(r["iterations"] - row["k"]) <= 0.10 * row["k"]
+    assert rel(r["x_norm"], row["x_norm"]) < 1e-12 and r["rel_residual"] <= 1e-11
+    assert len(row["x_samples"]) >= 20
+    for i, v in row["x_samples"].items():
+        assert rel(x[int(i)], v) < 1e-11, i
+
+
 @pytest.mark.parametrize("mode,p,variant", [(None, 1, 0), (1, 2, 0), (1, 4, 0), (1, 8, 0), (None, 1, 20441), (1, 8, 20241),
                                             (1, 8, 10822), (1, 8, 10442), (1, 8, 10444), (1, 4, 10824)])
 def test_config3_n32768_500_iterations(gpu_pkg, reference_probe, mode, p, variant):

@@ -179,6 +179,19 @@ def test_mtx_oracle_run_to_convergence_is_pinned(reference_probe, oracle_large):
         assert rel(row["x_samples"][i], v) < 1e-12, i
 
 
+def test_config2_oracle_run_to_convergence_is_pinned(reference_probe, oracle_large):
+    """BASELINE.json configs[1]: generate_lap2d N = 10000 to convergence (make_oracle_large.py c10000:1, the dense
+    restatement; cg_main.cc:31-55) against the reference's recorded run: the same k = 607 here, the printed 7 digits of
+    ||x|| and ||Ax-b||/||b||; the last recurrence residual itself sits at rounding level (1.01e-10 vs 1.02e-10)."""
+    row = [q for q in oracle_large["converged"] if q["n"] == 10000 and q["psize"] == 1][0]
+    ref = [q for q in reference_probe["generated"] if q["n"] == 10000][0]
+    assert row["converged"] and row["residual_last"] < 1e-10 <= row["residual"]
+    assert abs(row["k"] - ref["k"]) <= 0.10 * ref["k"]
+    assert rel(row["x_norm"], ref["x_norm"]) < 1e-6 and rel(row["rel_residual"], ref["rel_residual"]) < 1e-2
+    assert rel(row["residual"], ref["residual"]) < 0.05
+    assert len(row["x_samples"]) >= 20
+
+
 # ---- Matrix-Market input surface -----------------------------------------------------------------------
 def test_mtx_fixture_is_the_reference_file(mtx_path):
     ref = os.path.join(REF, "lap2D_5pt_n100.mtx")
