@@ -403,6 +403,12 @@ cgx_status cgx_create(cgx_ctx **out, const cgx_config *cfg_in)
         ctx->mv.rank = cfg.rank;
         ctx->mv.acquire = cfg.p2p_no_acquire_fence ? 0 : 1;
         ctx->mv.base[cfg.rank] = ctx->mailbox;
+        // the fixed part of the layout (flag words, chunk flag words, the two small channels) never depends on the problem
+        ctx->mv.cflag_off = p2p_flag_bytes();
+        ctx->mv.data_off[0] = p2p_data0_off();
+        ctx->mv.slot_bytes[0] = 16;
+        ctx->mv.data_off[2] = ctx->mv.data_off[0] + 2L * cfg.nranks * 16;
+        ctx->mv.slot_bytes[2] = (long)cgx::kSlots * 8;
         if (cfg.nranks == 1) ctx->p2p_ready = true;
     }
     *out = ctx;
@@ -513,6 +519,64 @@ cgx_status cgx_p2p_selftest(cgx_ctx *ctx, int rounds, int *ok)
         for (int q = 0; q < P && good; ++q)
             for (int i = 0; i < count; ++i)
                 if (hdst[(size_t)q * count + i] != 1e6 * (q + 1) + 1e3 * r + i + 0.25) { good = false; break; }
+    }
+    // Second half: the exchange of the fused update kernel itself (k_update_xr_p2p's own device code: (peer, chunk) pushes,
+    // per-chunk flag words, lane-per-flag waits, system-scope reads) on a pattern whose sums are exact in any order: an uneven
+    // partition with two chunks per rank and the slice held as two column pieces.
+    if (good) {
+        // The second half lays the segment channel out differently, so every peer must be done READING its slots of the
+        // first half before anybody writes in the new layout: one exchange on channel 2 in between is that barrier (a rank
+        // finishes it only after every peer pushed its channel-2 data, which a peer does, in stream order, after its last
+        // channel-1 kernel -- the argument that makes a re-layout between two solves safe).
+        CGX_TRY(p2p_allgather(ctx, 2, dsrc, cgx::kSlots, ddst, cgx::kSlots, 1));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (check_p2p_error(ctx) != CGX_OK) good = false;
+    }
+    if (good) {
+        const int n_loc = 1000, n = P * n_loc + (P > 1 ? 7 : 0);           // the last rank owns 7 rows more (cg.cc:255-266)
+        const int rows = (me == P - 1) ? n - me * n_loc : n_loc, row0 = me * n_loc;
+        const int Sr = (n - (P - 1) * n_loc + 1) / 2 * 2, cpr = cgx::chunks_per_rank(Sr);
+        const int grid = cgx::update_xr_grid(n);
+        ctx->mv.slot_bytes[1] = ((long)(Sr + cpr + 1) * 8 + 15) / 16 * 16;
+        if ((size_t)(ctx->mv.data_off[1] + 2L * P * ctx->mv.slot_bytes[1]) > ctx->mailbox_bytes || P * cpr > cgx::kMaxChunkFlags)
+            return fail(ctx, CGX_ERR_P2P, "mailbox too small for the self-test");
+        cgx::SegView apv{nullptr, Sr + cpr + 1, Sr, n_loc, P, n, me, 0, 0, 0};
+        cgx::seg_finalize(&apv);
+        double *d_parts = nullptr, *d_ones = nullptr, *d_vals = nullptr, *d_sums = nullptr;
+        HIP_TRY(ctx, scratch.alloc(&d_parts, (size_t)2 * Sr * sizeof(double)));
+        HIP_TRY(ctx, scratch.alloc(&d_ones, (size_t)(n + 2) * sizeof(double)));
+        HIP_TRY(ctx, scratch.alloc(&d_vals, (size_t)n * sizeof(double)));
+        HIP_TRY(ctx, scratch.alloc(&d_sums, (size_t)grid * sizeof(double)));
+        std::vector<double> parts((size_t)2 * Sr, 0.0), ones((size_t)n + 2, 1.0), vals((size_t)n), sums((size_t)grid);
+        HIP_TRY(ctx, hipMemcpyAsync(d_ones, ones.data(), ones.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+        auto sent = [&](int q, int row, int r) { return 1e6 * (q + 1) + 1e3 * r + row + 0.5; };   // what rank q sends for its row
+        for (int r = 0; r < rounds && good; ++r) {
+            for (int row = 0; row < rows; ++row) {
+                parts[(size_t)row] = sent(me, row, r) - 0.5;     // piece 0
+                parts[(size_t)Sr + row] = 0.5;                    // piece 1
+            }
+            HIP_TRY(ctx, hipMemcpyAsync(d_parts, parts.data(), parts.size() * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(d_vals, 0, (size_t)n * sizeof(double), ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(d_sums, 0, (size_t)grid * sizeof(double), ctx->stream));
+            const unsigned long long epoch = ++ctx->p2p_epoch[1];
+            HIP_TRY(ctx, cgx::launch_chunk_exchange_selftest(n, rows, row0, d_ones, apv, cpr, ctx->mv, 1, epoch, ctx->p2p_timeout_ticks,
+                                                             ctx->d_p2p_err, d_parts, 2, Sr, d_vals, d_sums, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(vals.data(), d_vals, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(sums.data(), d_sums, (size_t)grid * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (check_p2p_error(ctx) != CGX_OK) { good = false; break; }
+            double total = 0.0;                                     // multiples of 0.5 far below 2^53: exact in any order
+            for (int q = 0; q < P; ++q) {
+                const int rows_q = (q == P - 1) ? n - q * n_loc : n_loc;
+                for (int row = 0; row < rows_q; ++row) total += sent(q, row, r);
+            }
+            for (int i = 0; i < n && good; ++i) {
+                const int q = std::min(i / n_loc, P - 1);
+                if (vals[(size_t)i] != sent(q, i - q * n_loc, r)) good = false;
+            }
+            for (int b = 0; b < grid && good; ++b)
+                if (sums[(size_t)b] != total) good = false;
+        }
     }
     *ok = good ? 1 : 0;
     return CGX_OK;

@@ -199,6 +199,12 @@ hipError_t launch_update_xr_p2p(int n, int rows, int row0, const double *p_new, 
                                 const MailboxView &mv, int chan, unsigned long long epoch, double *x, SegView rv, Scalars *sc,
                                 int parity, long long timeout_ticks, int *err, hipStream_t s,
                                 const double *ap_src, int split, long stride);
+// The exchange of launch_update_xr_p2p alone (the same device code), on caller data: vals[i] = the Ap element read for
+// global row i (n doubles), sums[wg] = the folded chunk partials as workgroup wg saw them (update_xr_grid(n) doubles).
+hipError_t launch_chunk_exchange_selftest(int n, int rows, int row0, const double *p_like, SegView apv, int cpr,
+                                          const MailboxView &mv, int chan, unsigned long long epoch, long long timeout_ticks,
+                                          int *err, const double *ap_src, int split, long stride, double *vals, double *sums,
+                                          hipStream_t s);
 // Workgroups of k_update_xr_p2p the device keeps resident at once (occupancy x CUs): its grid must not exceed this, since
 // its workgroups wait for each other inside the kernel.
 hipError_t update_xr_p2p_resident_limit(int device, int *workgroups);

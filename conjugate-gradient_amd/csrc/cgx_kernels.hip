@@ -1307,6 +1307,97 @@ __global__ __launch_bounds__(256) void k_mailbox_allgather(MailboxView mv, int c
 // boundary between exchange and update.  All workgroups must be co-resident (the host checks the occupancy): pushers
 // never wait before they have pushed, so every flag a workgroup polls is raised by a workgroup that is running.
 // ------------------------------------------------------------------------------------------------
+// The exchange half of that kernel as device functions, so that the self-test of the transport (k_chunk_exchange_selftest,
+// the gate in front of every P2P run) executes EXACTLY the stores, fences, flag words, polls and loads of the production
+// kernel, not a look-alike.
+struct ChunkItem {      // one (peer, chunk) pair of this workgroup, loads issued
+    int peer, c, row;
+    d2 a, pp;
+};
+
+__device__ __forceinline__ ChunkItem chunk_fetch(int pr, int cpr, const double *__restrict__ ap_src, int split, long part_stride,
+                                                 int Sr, const double *__restrict__ p_loc, int rows)
+{
+    ChunkItem it;
+    it.peer = pr / cpr;
+    it.c = pr - it.peer * cpr;
+    it.row = (it.c * 256 + (int)threadIdx.x) * 2;                     // this thread's pair of rows of MY slice
+    it.pp = chunk_p(p_loc, it.row, rows);
+    it.a = chunk_pair(ap_src, split, part_stride, it.row, Sr);
+    return it;
+}
+
+// [chunk of Ap | its p.Ap partial] into the peer's slot, then the peer's flag word (me, chunk).
+// Release: the barrier orders every wave's stores before lane 0's system-scope release store of the flag (workgroup
+// release + barrier, then one system release: cumulative), instead of a system-scope fence in all four waves.
+__device__ __forceinline__ void chunk_publish(const MailboxView &mv, int chan, unsigned long long epoch, int cpr, int Sr,
+                                              const ChunkItem &it, double *lds)
+{
+    const int P = mv.nranks, me = mv.rank, par = (int)(epoch & 1);
+    const double d = chunk_dot<4>(it.pp, it.a, lds);                  // local part of MPI_Allreduce(p.Ap), cg.cc:105-106
+    double *out = reinterpret_cast<double *>(mv.base[it.peer] + mv.data_off[chan] + ((long)par * P + me) * mv.slot_bytes[chan]);
+    if (it.row < Sr) *reinterpret_cast<d2 *>(out + it.row) = it.a;
+    if (threadIdx.x == 0) out[Sr + it.c] = d;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        __hip_atomic_store(reinterpret_cast<unsigned long long *>(mv.base[it.peer] + mv.cflag_off) + (me * cpr + it.c), epoch,
+                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Lane f waits for flag word f = (source rank, chunk) of MY mailbox (bounded by the 100 MHz wall clock), then ONE
+// system-scope acquire per polling wave, drained before the caller's barrier releases the other waves (the consumer form of
+// the guide: relaxed polls -> one acquire -> s_waitcnt vmcnt(0) -> barrier -> loads).  Every load of handed-off bytes
+// afterwards is a system-scope load as well, so nothing rests on one mechanism alone when the peer's stores arrive over
+// xGMI instead of from a process on the same GPU.  Returns 0 in the lanes whose wait expired.
+__device__ __forceinline__ int chunk_wait_all(const MailboxView &mv, unsigned long long epoch, int npairs, long long timeout_ticks,
+                                              int *err)
+{
+    int ok = 1;
+    const unsigned long long *flags = reinterpret_cast<const unsigned long long *>(mv.base[mv.rank] + mv.cflag_off);
+    for (int f = threadIdx.x; f < npairs; f += 256) {
+        const long long t0 = wall_clock64();
+        // relaxed polls (an acquire per poll would invalidate caches every time round: 2-3x slower per hop)
+        while (__hip_atomic_load(flags + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+            __builtin_amdgcn_s_sleep(4);
+            if (wall_clock64() - t0 > timeout_ticks) {
+                ok = 0;
+                atomicExch(err, 1);
+                break;
+            }
+        }
+    }
+    if (mv.acquire && ((int)threadIdx.x & ~63) < npairs) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    return ok;
+}
+
+__device__ __forceinline__ const unsigned long long *chunk_slot(const MailboxView &mv, int chan, unsigned long long epoch, int q)
+{
+    return reinterpret_cast<const unsigned long long *>(mv.base[mv.rank] + mv.data_off[chan]) +
+           ((long)(epoch & 1) * mv.nranks + q) * (mv.slot_bytes[chan] / 8);
+}
+
+// this thread's share of all ranks' chunk partials, one fixed order (the caller block-reduces)
+__device__ __forceinline__ double chunk_read_partials(const MailboxView &mv, int chan, unsigned long long epoch, int cpr, int Sr,
+                                                      int npairs)
+{
+    double cs = 0.0;
+    for (int f = threadIdx.x; f < npairs; f += 256) {
+        const int q = f / cpr, c = f - q * cpr;
+        cs += __longlong_as_double((long long)__hip_atomic_load(chunk_slot(mv, chan, epoch, q) + Sr + c, __ATOMIC_RELAXED,
+                                                                  __HIP_MEMORY_SCOPE_SYSTEM));
+    }
+    return cs;
+}
+
+__device__ __forceinline__ double chunk_read_ap(const MailboxView &mv, int chan, unsigned long long epoch, int q, int off)
+{
+    return __longlong_as_double((long long)__hip_atomic_load(chunk_slot(mv, chan, epoch, q) + off, __ATOMIC_RELAXED,
+                                                              __HIP_MEMORY_SCOPE_SYSTEM));
+}
+
 __global__ __launch_bounds__(256) void k_update_xr_p2p(int n, int rows, int row0, const double *__restrict__ p_new,
                                                         SegView apv, int cpr, MailboxView mv, int chan,
                                                         unsigned long long epoch, double *__restrict__ x, SegView rv,
@@ -1315,7 +1406,7 @@ __global__ __launch_bounds__(256) void k_update_xr_p2p(int n, int rows, int row0
 {
     __shared__ double lds[4];
     double *r = rv.base;
-    const int tid = threadIdx.x, P = mv.nranks, me = mv.rank;
+    const int tid = threadIdx.x, P = mv.nranks;
     const int done = sc->done;
     // (an atomic load, not a volatile one: the compiler waits for a volatile load on the spot -- a whole memory round trip
     // at the top of the kernel with nothing else in flight, seen in the ISA)
@@ -1327,81 +1418,25 @@ __global__ __launch_bounds__(256) void k_update_xr_p2p(int n, int rows, int row0
     double r_i = 0.0, p_i = 0.0, x_i = 0.0;
     if (in) r_i = r[i];
     if (own) { p_i = p_new[i]; x_i = x[li]; }
-    const int par = (int)(epoch & 1);
-    const long slot = mv.slot_bytes[chan];
     const int npairs = P * cpr;
     // the first (peer, chunk) pair of this workgroup: its loads go out with the ones above, ahead of the first wait
     int pr = blockIdx.x;
-    int peer = 0, c = 0, row = 0;
-    d2 a{0.0, 0.0}, pp{0.0, 0.0};
-    if (pr < npairs) {                                               // uniform per workgroup
-        peer = pr / cpr;
-        c = pr - peer * cpr;
-        row = (c * 256 + tid) * 2;                                   // this thread's pair of rows of MY slice
-        pp = chunk_p(p_new + row0, row, rows);
-        a = chunk_pair(ap_src, split, part_stride, row, apv.Sr);
-    }
+    ChunkItem it{};
+    if (pr < npairs) it = chunk_fetch(pr, cpr, ap_src, split, part_stride, apv.Sr, p_new + row0, rows);   // uniform per workgroup
     // `done` is identical on every rank (r.r is bit-identical), so either all ranks exchange or none does
     if (__syncthreads_or(done | had_err)) return;
     while (pr < npairs) {
-        const double d = chunk_dot<4>(pp, a, lds);                    // local part of MPI_Allreduce(p.Ap), cg.cc:105-106
-        double *out = reinterpret_cast<double *>(mv.base[peer] + mv.data_off[chan] + ((long)par * P + me) * slot);
-        if (row < apv.Sr) *reinterpret_cast<d2 *>(out + row) = a;
-        if (tid == 0) out[apv.Sr + c] = d;
-        // Release: the barrier orders every wave's stores before lane 0's system-scope release store of the flag (workgroup
-        // release + barrier, then one system release: cumulative), instead of a system-scope fence in all four waves.
-        __syncthreads();
-        if (tid == 0)
-            __hip_atomic_store(reinterpret_cast<unsigned long long *>(mv.base[peer] + mv.cflag_off) + (me * cpr + c), epoch,
-                               __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        chunk_publish(mv, chan, epoch, cpr, apv.Sr, it, lds);
         pr += gridDim.x;
-        if (pr < npairs) {
-            peer = pr / cpr;
-            c = pr - peer * cpr;
-            row = (c * 256 + tid) * 2;
-            pp = chunk_p(p_new + row0, row, rows);
-            a = chunk_pair(ap_src, split, part_stride, row, apv.Sr);
-        }
+        if (pr < npairs) it = chunk_fetch(pr, cpr, ap_src, split, part_stride, apv.Sr, p_new + row0, rows);
     }
-    // every workgroup: lane f waits for flag word f = (source rank, chunk) of MY mailbox (bounded by the 100 MHz wall clock)
-    int ok = 1;
-    {
-        const unsigned long long *flags = reinterpret_cast<const unsigned long long *>(mv.base[me] + mv.cflag_off);
-        for (int f = tid; f < npairs; f += 256) {
-            const long long t0 = wall_clock64();
-            // relaxed polls (an acquire per poll would invalidate caches every time round: 2-3x slower per hop)
-            while (__hip_atomic_load(flags + f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
-                __builtin_amdgcn_s_sleep(4);
-                if (wall_clock64() - t0 > timeout_ticks) {
-                    ok = 0;
-                    atomicExch(err, 1);
-                    break;
-                }
-            }
-        }
-    }
-    // ONE system-scope acquire per polling wave, drained before the barrier releases the others (the consumer form of the
-    // guide: relaxed polls -> one acquire -> s_waitcnt vmcnt(0) -> barrier -> loads).  Every load of handed-off bytes
-    // below is a system-scope load as well, so nothing here rests on one mechanism alone when the peer's stores arrive
-    // over xGMI instead of from a process on the same GPU.
-    if (mv.acquire && (tid & ~63) < npairs) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
+    const int ok = chunk_wait_all(mv, epoch, npairs, timeout_ticks, err);
     if (!__syncthreads_and(ok)) return;
-    const unsigned long long *box = reinterpret_cast<const unsigned long long *>(mv.base[me] + mv.data_off[chan]);
-    const long slot_w = slot / 8;
-    double cs = 0.0;
-    for (int f = tid; f < npairs; f += 256) {                        // all ranks' chunk partials, one fixed order
-        const int q = f / cpr, c = f - q * cpr;
-        cs += __longlong_as_double((long long)__hip_atomic_load(box + ((long)par * P + q) * slot_w + apv.Sr + c, __ATOMIC_RELAXED,
-                                                                  __HIP_MEMORY_SCOPE_SYSTEM));
-    }
+    const double cs = chunk_read_partials(mv, chan, epoch, cpr, apv.Sr, npairs);
     double ap_i = 0.0;
     if (in) {
         const int q = (P > 1) ? seg_owner(apv, i) : 0;
-        ap_i = __longlong_as_double((long long)__hip_atomic_load(box + ((long)par * P + q) * slot_w + (i - q * apv.n_loc),
-                                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+        ap_i = chunk_read_ap(mv, chan, epoch, q, i - q * apv.n_loc);
     }
     const double conj = block_sum<4>(cs, lds);                       // bit-identical on every rank (cg.cc:106)
     const double alpha = safeguarded_alpha(rsold, conj);             // cg.cc:107
@@ -1414,6 +1449,40 @@ __global__ __launch_bounds__(256) void k_update_xr_p2p(int n, int rows, int row0
     if (own) x[li] = fma(alpha, p_i, x_i);                            // cg.cc:110
     rr = block_sum<4>(rr, lds);
     if (tid == 0) r[rv.Sr + blockIdx.x] = rr;
+}
+
+// The exchange of k_update_xr_p2p alone, on a pattern: every thread stores the Ap element it read for its row to
+// vals[i], every workgroup the folded partials to sums[blockIdx.x].  cgx_p2p_selftest compares both with what every rank
+// must have sent.
+__global__ __launch_bounds__(256) void k_chunk_exchange_selftest(int n, int rows, int row0, const double *__restrict__ p_like,
+                                                                  SegView apv, int cpr, MailboxView mv, int chan,
+                                                                  unsigned long long epoch, long long timeout_ticks, int *err,
+                                                                  const double *__restrict__ ap_src, int split, long part_stride,
+                                                                  double *__restrict__ vals, double *__restrict__ sums)
+{
+    __shared__ double lds[4];
+    const int tid = threadIdx.x, P = mv.nranks;
+    const int had_err = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int i = blockIdx.x * 256 + tid;
+    const int npairs = P * cpr;
+    int pr = blockIdx.x;
+    ChunkItem it{};
+    if (pr < npairs) it = chunk_fetch(pr, cpr, ap_src, split, part_stride, apv.Sr, p_like + row0, rows);
+    if (__syncthreads_or(had_err)) return;
+    while (pr < npairs) {
+        chunk_publish(mv, chan, epoch, cpr, apv.Sr, it, lds);
+        pr += gridDim.x;
+        if (pr < npairs) it = chunk_fetch(pr, cpr, ap_src, split, part_stride, apv.Sr, p_like + row0, rows);
+    }
+    const int ok = chunk_wait_all(mv, epoch, npairs, timeout_ticks, err);
+    if (!__syncthreads_and(ok)) return;
+    const double cs = chunk_read_partials(mv, chan, epoch, cpr, apv.Sr, npairs);
+    if (i < n) {
+        const int q = (P > 1) ? seg_owner(apv, i) : 0;
+        vals[i] = chunk_read_ap(mv, chan, epoch, q, i - q * apv.n_loc);
+    }
+    const double conj = block_sum<4>(cs, lds);
+    if (tid == 0) sums[blockIdx.x] = conj;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1773,6 +1842,17 @@ hipError_t launch_update_xr_p2p(int n, int rows, int row0, const double *p_new, 
     if (cpr != chunks_per_rank(apv.Sr) || (long)mv.nranks * cpr > kMaxChunkFlags) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_update_xr_p2p, dim3(update_xr_grid(n)), dim3(256), 0, s, n, rows, row0, p_new, apv, cpr, mv, chan,
                        epoch, x, rv, sc, parity, timeout_ticks, err, ap_src, split, stride);
+    return hipGetLastError();
+}
+
+hipError_t launch_chunk_exchange_selftest(int n, int rows, int row0, const double *p_like, SegView apv, int cpr,
+                                          const MailboxView &mv, int chan, unsigned long long epoch, long long timeout_ticks,
+                                          int *err, const double *ap_src, int split, long stride, double *vals, double *sums,
+                                          hipStream_t s)
+{
+    if (cpr != chunks_per_rank(apv.Sr) || (long)mv.nranks * cpr > kMaxChunkFlags || split > 8) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_chunk_exchange_selftest, dim3(update_xr_grid(n)), dim3(256), 0, s, n, rows, row0, p_like, apv, cpr, mv,
+                       chan, epoch, timeout_ticks, err, ap_src, split, stride, vals, sums);
     return hipGetLastError();
 }
 

@@ -2,7 +2,9 @@
 
 It runs the row-block CG with the SAME exchange protocol libcgx uses (conjugate-gradient_amd/csrc/
 cgx_solve.cpp: enqueue_iteration / gather_segments), with the oracle's GEMV standing in for K1:
-  * one all-gather per iteration of equal segments [Ap slice | p.Ap partial]; p.Ap = rank-ordered sum;
+  * one all-gather per iteration of equal segments [Ap slice | one p.Ap partial per 512-row chunk of the slice]
+    (cgx_kernels.hip "Chunks": k_prefold_ap / the pushers of the fused P2P update); p.Ap = sum over (rank, chunk) in one
+    fixed order;
   * r and p are replicated: every rank updates all of r and reduces r.r itself, identically;
   * break: every rank must see bit-identical r.r and leave the loop at the same k.
 Rank 0 compares against the in-process oracle with the same psize and writes a JSON verdict.
@@ -50,19 +52,25 @@ def main():
     tol = 1e-10
     x = np.zeros(rows)
 
-    def exchange(Ap_local, partial):
-        seg = np.zeros(Sr + 1)
+    CHUNK = 512                                         # cgx::kChunkRows
+    cpr = max((Sr + CHUNK - 1) // CHUNK, 1)             # chunks per rank, the same on every rank
+
+    def exchange(Ap_local, p_local):
+        seg = np.zeros(Sr + cpr)
         seg[:rows] = Ap_local
-        seg[Sr] = partial
+        for c in range(cpr):                            # one p.Ap partial per chunk of the slice (cg.cc:105)
+            lo, hi = min(c * CHUNK, rows), min((c + 1) * CHUNK, rows)
+            seg[Sr + c] = O.dot(p_local[lo:hi], Ap_local[lo:hi]) if (p_local is not None and hi > lo) else 0.0
         allseg = gather_segments(seg, counts, rank, world)
         Ap_full = np.concatenate([allseg[q, :counts[q]] for q in range(world)])
-        conj = allseg[0, Sr]
-        for q in range(1, world):                       # rank order, same on every rank
-            conj = conj + allseg[q, Sr]
+        conj = 0.0
+        for q in range(world):                          # (rank, chunk) order, same on every rank (cg.cc:106)
+            for c in range(cpr):
+                conj = conj + allseg[q, Sr + c]
         return Ap_full, conj
 
     # initial residual with x0 = 0 (cg.cc:79-92): r, p replicated on every rank
-    Ap_full, _ = exchange(O.gemv(A, np.zeros(n)) if rows else np.zeros(0), 0.0)
+    Ap_full, _ = exchange(O.gemv(A, np.zeros(n)) if rows else np.zeros(0), None)
     r = b - Ap_full
     p = r.copy()
     rsold = O.dot(r, r)
@@ -71,7 +79,7 @@ def main():
     while k < max_iter:
         Ap = O.gemv(A, p) if rows else np.zeros(0)
         pl = p[r0:r0 + rows]
-        Ap_full, conj = exchange(Ap, O.dot(pl, Ap) if rows else 0.0)
+        Ap_full, conj = exchange(Ap, pl)
         safe = rsold * NEARZERO
         alpha = rsold / (safe if conj < safe else conj)  # std::max(conj, safe), cg.cc:107
         x = x + alpha * pl

@@ -20,7 +20,8 @@ def run_world(world, n, max_iter, tmp_path, port):
     return json.load(open(out))
 
 
-@pytest.mark.parametrize("world,n,max_iter,port", [(2, 512, 60, 29611), (2, 257, 400, 29612), (3, 200, 50, 29613)])
+@pytest.mark.parametrize("world,n,max_iter,port", [(2, 512, 60, 29611), (2, 257, 400, 29612), (3, 200, 50, 29613),
+                                                   (2, 2500, 40, 29614)])          # three 512-row chunks per rank
 def test_rowblock_protocol_over_gloo(tmp_path, world, n, max_iter, port):
     v = run_world(world, n, max_iter, tmp_path, port)
     assert v["ranks_agree"], v                       # same break decision, bit-identical rsnew on every rank
