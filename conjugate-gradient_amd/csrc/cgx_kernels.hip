@@ -276,7 +276,10 @@ __device__ __forceinline__ d2 make_p(const SegView &sv, double beta, d2 p_old, i
 // vector operands are fetched before the sweep.  (A two-trips-deep software pipeline of the sweep was built and
 // measured in round 2: no faster -- 157.0 us against 157.2 on the 4096 x 32768 shard -- and dropped again; what limits
 // this shape is the access pattern itself, tools/hbm_rows_bw.hip.)
-template <int R, int U, int WAVES, int MODE, bool LIGHT = false>
+// PART = false (one-round form only): nobody consumes this launch's per-workgroup p.Ap partials (chunked exchange: the
+// consumer of Ap reduces one partial per 512-row chunk itself), so the epilogue's two operand loads, the product and the
+// store are left out.
+template <int R, int U, int WAVES, int MODE, bool LIGHT = false, bool PART = true>
 __global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 1))) void k_gemv_colsplit(const double *__restrict__ A, long lda, int ncols_all, int rows,
                                                                int row0_global, const double *__restrict__ v,
                                                                double *__restrict__ p_new, SegView sv,
@@ -391,7 +394,7 @@ __global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 
         constexpr bool HOIST = LIGHT || R * U <= 8;
         HeadLoads hl{};
         if constexpr (FUSED) hl = head_issue(sc, sv, k);
-        if constexpr (LIGHT) {
+        if constexpr (LIGHT && PART) {
             long er = row0 + (lane & (R - 1));
             if (er > rows - 1) er = rows - 1;
             if (er < 0) er = 0;
@@ -458,17 +461,21 @@ __global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 
             const long row = row0 + lane;
             if (row < rows) {
                 Ap[row] = s;
-                const int j = row0_global + (int)row;
-                // (LIGHT: lane < R holds the operands of row row0 + lane, fetched ahead of the sweep)
-                double pl = LIGHT ? ep_v : v[j];
-                if constexpr (FUSED) pl = fma(beta, pl, LIGHT ? ep_r : seg_load(sv, j));   // same bits as the stored p_new[j]
-                d = pl * s;                                                 // cg.cc:105
+                if constexpr (PART) {
+                    const int j = row0_global + (int)row;
+                    // (LIGHT: lane < R holds the operands of row row0 + lane, fetched ahead of the sweep)
+                    double pl = LIGHT ? ep_v : v[j];
+                    if constexpr (FUSED) pl = fma(beta, pl, LIGHT ? ep_r : seg_load(sv, j));   // same bits as the stored p_new[j]
+                    d = pl * s;                                                 // cg.cc:105
+                }
             }
         }
-        d = group_sum<(R < 64 ? R : 64)>(d);   // only lanes 0..R-1 hold a term
-        // One partial per workgroup; K3 folds all of them (all ranks') in a fixed order.  No ticket here:
-        // 4096 workgroups taking a returning atomic on one word cost 3-10 % of K1 (measured).
-        if (lane == 0) partials[blockIdx.x] = d;
+        if constexpr (PART) {
+            d = group_sum<(R < 64 ? R : 64)>(d);   // only lanes 0..R-1 hold a term
+            // One partial per workgroup; K3 folds all of them (all ranks') in a fixed order.  No ticket here:
+            // 4096 workgroups taking a returning atomic on one word cost 3-10 % of K1 (measured).
+            if (lane == 0) partials[blockIdx.x] = d;
+        }
     }
 }
 
@@ -1603,8 +1610,12 @@ hipError_t launch_shape(const GemvPlan &pl, const GemvArgs &g, hipStream_t s)
 template <int R, int U, int MODE>
 hipError_t launch_light(const GemvPlan &pl, const GemvArgs &g, hipStream_t s)
 {
-    hipExtLaunchKernelGGL((k_gemv_colsplit<R, U, 4, MODE, true>), dim3(pl.grid / pl.split * g.split), dim3(256), 0, s, g.e0, g.e1, 0, g.A, g.lda,
-                          pl.ncols, g.rows, g.row0, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol, g.split, g.ap_stride);
+    if (g.partials)
+        hipExtLaunchKernelGGL((k_gemv_colsplit<R, U, 4, MODE, true, true>), dim3(pl.grid / pl.split * g.split), dim3(256), 0, s, g.e0, g.e1, 0, g.A, g.lda,
+                              pl.ncols, g.rows, g.row0, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol, g.split, g.ap_stride);
+    else   // nobody folds this launch's per-workgroup p.Ap partials (chunked exchange)
+        hipExtLaunchKernelGGL((k_gemv_colsplit<R, U, 4, MODE, true, false>), dim3(pl.grid / pl.split * g.split), dim3(256), 0, s, g.e0, g.e1, 0, g.A, g.lda,
+                              pl.ncols, g.rows, g.row0, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol, g.split, g.ap_stride);
     return hipGetLastError();
 }
 

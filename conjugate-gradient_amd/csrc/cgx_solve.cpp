@@ -161,8 +161,9 @@ cgx_status run_gemv_fused(cgx_ctx *ctx, Shard &s, int k)
                                                 s.rv, s.Ap(), s.k1_part(), s.sc, k, ctx->tol, ctx->stream, e0, e1));
     else
         HIP_TRY(ctx, cgx::launch_gemv_fused(s.plan, s.A, ctx->lda, s.rows, s.row0, s.p[k & 1], s.p[(k + 1) & 1], s.rv,
-                                            s.plan.split > 1 ? s.ap_parts : s.Ap(), s.k1_part(), s.sc, k, ctx->tol, ctx->stream,
-                                            e0, e1, ctx->seg_Sr));
+                                            s.plan.split > 1 ? s.ap_parts : s.Ap(),
+                                            (ctx->chunked && s.plan.light) ? nullptr : s.k1_part(),   // chunked: nobody folds K1's own partials
+                                            s.sc, k, ctx->tol, ctx->stream, e0, e1, ctx->seg_Sr));
     if (m1) HIP_TRY(ctx, hipEventRecord(m1, ctx->stream));
     return CGX_OK;
 }

@@ -161,3 +161,23 @@ def test_rank0_prints_a_line_when_a_peer_dies(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(no_gpu_env(), MASTER_ADDR="127.0.0.1"))
     d = one_line(r.stdout)
     assert r.returncode != 0 and d["value"] is None and d["n_gpus"] == 2 and "error" in d
+
+
+def test_committed_traffic_rows_name_the_kernel_form_they_were_collected_on():
+    """profiles/k1_hbm_traffic.json (written by tools/pmc_k1.sh alone): every row carries the K1 plan, the plan agrees with the
+    kernel name rocprofv3 recorded (template arguments R, U, ..., light), the traffic is the guide's formula of the two
+    counters, and the headline shapes are all there."""
+    import re
+    doc = json.load(open(os.path.join(ROOT, "profiles", "k1_hbm_traffic.json")))
+    assert "rows_unsplit_shards" not in doc
+    seen = set()
+    for r in doc["rows"]:
+        pl = r["plan"]
+        m = re.search(r"k_gemv_colsplit<(\d+), (\d+), \d+, 1(?:, (true|false))?(?:, (?:true|false))?>", r["kernel"])
+        assert m and int(m.group(1)) == pl["R"] and int(m.group(2)) == pl["U"] and (m.group(3) == "true") == bool(pl["light"]), r["kernel"]
+        rows = r["n"] // r["nranks"]
+        assert r["algorithmic_bytes_per_launch"] == 8.0 * (rows * r["n"] + r["n"] + rows)
+        assert abs(r["hbm_bytes_per_launch"] - (r["FETCH_SIZE_KB_mean"] * 2048 + r["WRITE_SIZE_KB_mean"] * 1024)) < 1.0
+        assert 1.0 <= r["traffic_over_algorithmic"] < 1.01 and r["launches_sampled"] >= 100
+        seen.add((r["n"], r["nranks"]))
+    assert {(32768, 1), (32768, 2), (32768, 4), (32768, 8), (16384, 1)} <= seen

@@ -30,7 +30,7 @@ done
 python3 - "$R/gpurun_out" <<'PY'
 import csv, json, re, sys, os
 out = sys.argv[1]
-fused = re.compile(r"k_gemv_colsplit<(\d+), (\d+), \d+, 1(?:, (true|false))?>")
+fused = re.compile(r"k_gemv_colsplit<(\d+), (\d+), \d+, 1(?:, (true|false))?(?:, (?:true|false))?>")
 def collect(raw, counter, dst):
     """mean of `counter` over the fused K1 dispatches; writes the CSV cut down to those rows"""
     vals, names, keep, header = [], set(), [], None
