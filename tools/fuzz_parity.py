@@ -9,7 +9,8 @@ pkg = g.load_package(); O = g.load_oracle()
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 VARIANTS = [0, 0, 0, 10821, 10811, 10441, 10421, 10241, 10281, 10181, 11611, 20821, 20441, 20241, 20181,
-            10822, 10842, 10442, 10282, 11612]   # ..2: the one-round form of the column-split K1
+            10822, 10842, 10442, 10282, 11612,   # ..2: the one-round form of the column-split K1
+            10823, 10824, 10825, 10444, 10445]   # ..3/4/5: the same with 2 / 4 / 8 XCD-affine column pieces (chunked consumer)
 BANDED_VARIANTS = [0, 30001, 30002]        # K1b: default / direct / LDS windows
 t0 = time.time(); cases = 0; worst = 0.0
 while time.time() - t0 < budget:
