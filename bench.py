@@ -62,6 +62,10 @@ def parse_args():
     ap.add_argument("--profile-every", type=int, default=0,
                     help="event-time every n-th K1 launch (default: when steps <= 64 every launch on one GPU, so that a "
                          "short window still gives >= 16 samples, every 2nd on several; else 4 on one GPU, 8 on several)")
+    ap.add_argument("--profile-update", action="store_true",
+                    help="also event-time the update kernel (K3, or K3 with the exchange inside) on the launches whose K1 is timed; "
+                         "default: on for several GPUs (its duration then holds the wait for the peers = the cost of the exchange), "
+                         "off on one (a timed dispatch costs ~5 us of stream time)")
     ap.add_argument("--no-solve-window", action="store_true", help="skip the extra untimed solve() through the reference's window")
     ap.add_argument("--wireup-timeout", type=float, default=float(os.environ.get("CGX_BENCH_WIREUP_TIMEOUT", "90")),
                     help="seconds one transport's wire-up stage may take before that transport is dropped")
@@ -294,7 +298,7 @@ class Bench:
         peer is bounded by --wireup-timeout."""
         pkg, dist, world, rank, n, args = self.pkg, self.dist, self.world, self.rank, self.n, self.args
         common = dict(nranks=world, rank=rank, device=self.local_rank, gemv_variant=args.variant, lda_pad=args.lda_pad,
-                      profile_gemv=self.profile_every)
+                      profile_gemv=self.profile_every, profile_update=bool(self.profile_every) and (world > 1 or args.profile_update))
         box = {"s": None, "uid": None, "handle": None}
         self.state["stage"] = "wire-up of transport " + transport
 
@@ -404,6 +408,7 @@ class Bench:
         res, samples = None, None
         try:
             samples = s.gemv_samples() if self.profile_every else np.zeros(0)
+            self.update_samples = s.update_samples() if self.profile_every else np.zeros(0)
             res = s.solve_end(x)
         except Exception as e:             # noqa: BLE001
             self.log("solve_end failed: %s" % e)
@@ -532,6 +537,8 @@ class Bench:
         my_rows = counts[rank]
         k1_rows = self.gather_rows([my_rows, res["gemv_launches"], res["gemv_discarded"], res["gemv_ms_min"],
                                     res["gemv_ms_median"], res["gemv_ms_avg"], res["gemv_ms_max"]])
+        us = sorted(float(v) for v in getattr(self, "update_samples", []))
+        upd_rows = self.gather_rows([float(len(us)), us[0] if us else 0.0, us[len(us) // 2] if us else 0.0, us[-1] if us else 0.0])
         dev_ms = self.max_over_ranks(res.get("steps_device_ms", 0.0))
         info = solver.comm_info()
         devices = self.gather_strings(info["device_id"])
@@ -609,6 +616,15 @@ class Bench:
         if world > 1:
             line["k1_per_rank"] = per_rank
             line["k1_slowest_rank"] = slowest["rank"] if slowest else None
+        if any(u[0] > 0 for u in upd_rows):
+            # the update kernel of the same iterations whose K1 was timed: K3, or (p2p) K3 with the exchange inside, whose
+            # duration holds the bounded wait for every peer's chunks -- what the exchange costs each rank (cg.cc:106,135-136)
+            line["update_kernel"] = {
+                "kernel": "k_update_xr_p2p (K3 with the exchange inside)" if transport == "p2p" else "k_update_xr (K3)",
+                "timing": "HIP events bound to the dispatch, the launches whose K1 was timed",
+                "per_rank": [{"rank": q, "launches_timed": int(u[0]), "min_ms": u[1], "median_ms": u[2], "max_ms": u[3]}
+                             for q, u in enumerate(upd_rows)],
+            }
         if dev_ms > 0:
             # the same K steps on the device's own clock (markers in front of the first and behind the last kernel of
             # the timed call, max over ranks): what is left to ms_per_step is launch latency and the final synchronise

@@ -26,6 +26,7 @@ EXPORTS = [
     "cgx_init_source_term", "cgx_set_source_term", "cgx_set_max_iter", "cgx_set_tolerance", "cgx_get_size",
     "cgx_get_matrix_format",
     "cgx_solve", "cgx_solve_begin", "cgx_solve_steps", "cgx_solve_end", "cgx_get_gemv_samples",
+    "cgx_get_update_samples",
     "cgx_probe_gemv", "cgx_probe_time_gemv", "cgx_probe_vector_ops", "cgx_probe_get_matrix_rows",
     "cgx_probe_get_source_term", "cgx_probe_set_fault_after", "cgx_probe_set_resident_limit",
 ]
@@ -35,7 +36,7 @@ class Config(C.Structure):
     _fields_ = [
         ("struct_version", C.c_int), ("comm_mode", C.c_int), ("device", C.c_int), ("rank", C.c_int),
         ("nranks", C.c_int), ("unique_id", C.c_ubyte * UNIQUE_ID_BYTES), ("gemv_variant", C.c_int),
-        ("lda_pad", C.c_int), ("check_every", C.c_int), ("profile_gemv", C.c_int), ("reserved0", C.c_int),
+        ("lda_pad", C.c_int), ("check_every", C.c_int), ("profile_gemv", C.c_int), ("profile_update", C.c_int),
         ("p2p_mailbox_kib", C.c_int), ("p2p_timeout_ms", C.c_int), ("p2p_separate_exchange", C.c_int),
         ("matrix_format", C.c_int), ("profile_first", C.c_int), ("profile_markers", C.c_int),
         ("p2p_no_acquire_fence", C.c_int), ("reserved", C.c_int * 1),
@@ -112,6 +113,7 @@ def lib():
         L.cgx_solve_steps.argtypes = [vp, C.c_int, ip]
         L.cgx_solve_end.argtypes = [vp, dp, C.POINTER(Result)]
         L.cgx_get_gemv_samples.argtypes = [vp, dp, C.c_int, ip]
+        L.cgx_get_update_samples.argtypes = [vp, dp, C.c_int, ip]
         L.cgx_probe_gemv.argtypes = [vp, dp, dp, dp]
         L.cgx_probe_time_gemv.argtypes = [vp, C.c_int, dp]
         L.cgx_probe_vector_ops.argtypes = [vp, C.c_int, C.c_double, C.c_double, dp, dp, dp, dp, dp]
@@ -159,7 +161,7 @@ class CGSolver:
     def __init__(self, comm_mode=COMM_SELF, nranks=1, rank=0, device=0, unique_id=None, gemv_variant=0,
                  lda_pad=-1, check_every=0, profile_gemv=False, p2p_timeout_ms=0, p2p_mailbox_kib=0,
                  p2p_separate_exchange=False, matrix_format=MATRIX_DENSE, profile_first=False,
-                 profile_markers=False, p2p_no_acquire_fence=False):
+                 profile_markers=False, p2p_no_acquire_fence=False, profile_update=False):
         L = lib()
         cfg = Config()
         L.cgx_config_init(C.byref(cfg))
@@ -171,6 +173,7 @@ class CGSolver:
         cfg.lda_pad = lda_pad
         cfg.check_every = check_every
         cfg.profile_gemv = int(profile_gemv)   # n > 0: every n-th K1 launch is event-timed
+        cfg.profile_update = 1 if profile_update else 0   # ... and the update kernel of the same iterations
         cfg.p2p_timeout_ms = p2p_timeout_ms
         cfg.p2p_mailbox_kib = p2p_mailbox_kib
         cfg.p2p_separate_exchange = 1 if p2p_separate_exchange else 0
@@ -316,6 +319,16 @@ class CGSolver:
         out = np.zeros(cnt.value, dtype=np.float64)
         if cnt.value:
             self._check(lib().cgx_get_gemv_samples(self._h, _dp(out), cnt.value, C.byref(cnt)))
+        return out
+
+    def update_samples(self):
+        """Durations (ms) of the event-timed update kernels (K3 / K3 with the exchange inside) of the most recent solve_steps
+        call, launch order (needs profile_gemv and profile_update)."""
+        cnt = C.c_int()
+        self._check(lib().cgx_get_update_samples(self._h, None, 0, C.byref(cnt)))
+        out = np.zeros(cnt.value, dtype=np.float64)
+        if cnt.value:
+            self._check(lib().cgx_get_update_samples(self._h, _dp(out), cnt.value, C.byref(cnt)))
         return out
 
     # -- kernel probes -------------------------------------------------------------------------------

@@ -596,6 +596,7 @@ cgx_status cgx_destroy(cgx_ctx *ctx)
         if (ctx->d_p2p_err) (void)hipFree(ctx->d_p2p_err);
     }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
+    for (auto e : ctx->upd_pool) (void)hipEventDestroy(e);
     for (auto e : ctx->steps_ev)
         if (e) (void)hipEventDestroy(e);
     for (auto e : ctx->flag_ev)

@@ -102,6 +102,10 @@ struct cgx_ctx {
     long long gemv_launches = 0, gemv_discarded = 0;
     long long gemv_seq = 0;              // K1 launches of the current cgx_solve_steps call
     std::vector<float> gemv_samples;     // their durations (ms), most recent steps call
+    bool gemv_timed_last = false;        // the most recent K1 launch was event-timed (the update kernel of that iteration follows suit)
+    std::vector<hipEvent_t> upd_pool;    // cfg.profile_update: event pairs around the update kernels of the timed iterations
+    size_t upd_used = 0;
+    std::vector<float> upd_samples;      // their durations (ms), most recent steps call
     hipEvent_t steps_ev[2] = {nullptr, nullptr};   // markers around the kernels of the most recent steps call (profiling on)
     bool steps_ev_pending = false;
     double steps_device_ms = 0;

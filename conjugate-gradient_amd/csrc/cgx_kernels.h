@@ -94,7 +94,8 @@ hipError_t launch_prefold_ap(const double *parts, int split, long stride, int ro
 // alpha = rsold / max(p.Ap, rsold*1e-14); x_sub += alpha p_sub (own rows); r -= alpha Ap for ALL n rows (r is
 // replicated, rv = [r (lda) | one r.r partial per K3 workgroup]); the next K1's head folds the partials.  cg.cc:105-116.
 hipError_t launch_update_xr(int n, int rows, int row0, const double *p_new, SegView apv, int tail_off, int tail_count,
-                            double *x, SegView rv, Scalars *sc, int parity, double *partials, hipStream_t s);
+                            double *x, SegView rv, Scalars *sc, int parity, double *partials, hipStream_t s,
+                            hipEvent_t e_start = nullptr, hipEvent_t e_stop = nullptr);   // optional: bound to the dispatch
 int update_xr_grid(int count);   // ceil(count/256), at most kMaxVectorGrid (above that the kernels stride over the rows)
 constexpr int kMaxVectorGrid = 1024;
 
@@ -198,7 +199,8 @@ hipError_t launch_mailbox_allgather(const MailboxView &mv, int chan, unsigned lo
 hipError_t launch_update_xr_p2p(int n, int rows, int row0, const double *p_new, SegView apv, int cpr,
                                 const MailboxView &mv, int chan, unsigned long long epoch, double *x, SegView rv, Scalars *sc,
                                 int parity, long long timeout_ticks, int *err, hipStream_t s,
-                                const double *ap_src, int split, long stride);
+                                const double *ap_src, int split, long stride, hipEvent_t e_start = nullptr,
+                                hipEvent_t e_stop = nullptr);
 // The exchange of launch_update_xr_p2p alone (the same device code), on caller data: vals[i] = the Ap element read for
 // global row i (n doubles), sums[wg] = the folded chunk partials as workgroup wg saw them (update_xr_grid(n) doubles).
 hipError_t launch_chunk_exchange_selftest(int n, int rows, int row0, const double *p_like, SegView apv, int cpr,

@@ -1671,14 +1671,15 @@ int update_xr_grid(int count)
 }
 
 hipError_t launch_update_xr(int n, int rows, int row0, const double *p_new, SegView apv, int tail_off, int tail_count,
-                            double *x, SegView rv, Scalars *sc, int parity, double *partials, hipStream_t s)
+                            double *x, SegView rv, Scalars *sc, int parity, double *partials, hipStream_t s, hipEvent_t e0,
+                            hipEvent_t e1)
 {
     if ((long)update_xr_grid(n) * 256 >= n)   // one row per thread: every dense problem
-        hipLaunchKernelGGL(k_update_xr, dim3(update_xr_grid(n)), dim3(256), 0, s, n, rows, row0, p_new, apv, tail_off,
-                           tail_count, x, rv, sc, parity, partials);
+        hipExtLaunchKernelGGL(k_update_xr, dim3(update_xr_grid(n)), dim3(256), 0, s, e0, e1, 0, n, rows, row0, p_new, apv, tail_off,
+                              tail_count, x, rv, sc, parity, partials);
     else
-        hipLaunchKernelGGL(k_update_xr_strided, dim3(update_xr_grid(n)), dim3(256), 0, s, n, rows, row0, p_new, apv,
-                           tail_off, tail_count, x, rv, sc, parity);
+        hipExtLaunchKernelGGL(k_update_xr_strided, dim3(update_xr_grid(n)), dim3(256), 0, s, e0, e1, 0, n, rows, row0, p_new, apv,
+                              tail_off, tail_count, x, rv, sc, parity);
     return hipGetLastError();
 }
 
@@ -1848,11 +1849,12 @@ hipError_t launch_dia_pack(const double *A, long lda, int n, int row0, int rows,
 hipError_t launch_update_xr_p2p(int n, int rows, int row0, const double *p_new, SegView apv, int cpr,
                                 const MailboxView &mv, int chan, unsigned long long epoch, double *x, SegView rv, Scalars *sc,
                                 int parity, long long timeout_ticks, int *err, hipStream_t s, const double *ap_src, int split,
-                                long stride)
+                                long stride, hipEvent_t e0, hipEvent_t e1)
 {
-    if (cpr != chunks_per_rank(apv.Sr) || (long)mv.nranks * cpr > kMaxChunkFlags) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_update_xr_p2p, dim3(update_xr_grid(n)), dim3(256), 0, s, n, rows, row0, p_new, apv, cpr, mv, chan,
-                       epoch, x, rv, sc, parity, timeout_ticks, err, ap_src, split, stride);
+    if (cpr != chunks_per_rank(apv.Sr) || (long)mv.nranks * cpr > kMaxChunkFlags || split < 1 || split > kMaxSplit)
+        return hipErrorInvalidValue;
+    hipExtLaunchKernelGGL(k_update_xr_p2p, dim3(update_xr_grid(n)), dim3(256), 0, s, e0, e1, 0, n, rows, row0, p_new, apv, cpr, mv,
+                          chan, epoch, x, rv, sc, parity, timeout_ticks, err, ap_src, split, stride);
     return hipGetLastError();
 }
 
@@ -1861,7 +1863,8 @@ hipError_t launch_chunk_exchange_selftest(int n, int rows, int row0, const doubl
                                           int *err, const double *ap_src, int split, long stride, double *vals, double *sums,
                                           hipStream_t s)
 {
-    if (cpr != chunks_per_rank(apv.Sr) || (long)mv.nranks * cpr > kMaxChunkFlags || split > 8) return hipErrorInvalidValue;
+    if (cpr != chunks_per_rank(apv.Sr) || (long)mv.nranks * cpr > kMaxChunkFlags || split < 1 || split > kMaxSplit)
+        return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_chunk_exchange_selftest, dim3(update_xr_grid(n)), dim3(256), 0, s, n, rows, row0, p_like, apv, cpr, mv,
                        chan, epoch, timeout_ticks, err, ap_src, split, stride, vals, sums);
     return hipGetLastError();
@@ -1881,6 +1884,7 @@ hipError_t update_xr_p2p_resident_limit(int device, int *workgroups)
 hipError_t launch_prefold_ap(const double *parts, int split, long stride, int rows, int Sr, const double *p_loc, double *dst,
                              double *tail, const Scalars *sc, hipStream_t s)
 {
+    if (split < 1 || split > kMaxSplit) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_prefold_ap, dim3(chunks_per_rank(Sr)), dim3(256), 0, s, parts, split, stride, rows, Sr, p_loc, dst, tail, sc);
     return hipGetLastError();
 }

@@ -111,6 +111,22 @@ cgx_status take_event(cgx_ctx *ctx, hipEvent_t *out)
     return CGX_OK;
 }
 
+// cfg.profile_update: an event pair for the update kernel of an iteration whose K1 was timed (first shard only: one
+// sample per iteration), or two null handles.
+cgx_status take_update_events(cgx_ctx *ctx, hipEvent_t *e0, hipEvent_t *e1)
+{
+    *e0 = *e1 = nullptr;
+    if (!ctx->cfg.profile_update || !ctx->gemv_timed_last || ctx->cfg.profile_markers) return CGX_OK;
+    while (ctx->upd_used + 2 > ctx->upd_pool.size()) {
+        hipEvent_t e;
+        HIP_TRY(ctx, hipEventCreate(&e));
+        ctx->upd_pool.push_back(e);
+    }
+    *e0 = ctx->upd_pool[ctx->upd_used++];
+    *e1 = ctx->upd_pool[ctx->upd_used++];
+    return CGX_OK;
+}
+
 }  // namespace
 
 namespace cgxi {
@@ -146,6 +162,7 @@ cgx_status run_gemv_fused(cgx_ctx *ctx, Shard &s, int k)
             timed = ((seq - 1) % every) == 0;
         }
     }
+    ctx->gemv_timed_last = timed;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (timed) {
         CGX_TRY(take_event(ctx, &e0));
@@ -175,6 +192,9 @@ void reset_gemv_stats(cgx_ctx *ctx)
     ctx->gemv_launches = ctx->gemv_discarded = 0;
     ctx->gemv_seq = 0;
     ctx->gemv_samples.clear();
+    ctx->gemv_timed_last = false;
+    ctx->upd_used = 0;
+    ctx->upd_samples.clear();
     ctx->steps_ev_pending = false;
     ctx->steps_device_ms = 0;
 }
@@ -192,6 +212,12 @@ cgx_status harvest_gemv_events(cgx_ctx *ctx)
         ctx->gemv_samples.push_back(ms);
     }
     ctx->ev_used = 0;
+    for (size_t i = 0; i + 1 < ctx->upd_used; i += 2) {
+        float ms = 0.f;
+        HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->upd_pool[i], ctx->upd_pool[i + 1]));
+        ctx->upd_samples.push_back(ms);
+    }
+    ctx->upd_used = 0;
     if (ctx->steps_ev_pending) {
         float ms = 0.f;
         HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->steps_ev[0], ctx->steps_ev[1]));
@@ -212,9 +238,11 @@ cgx_status enqueue_iteration(cgx_ctx *ctx, int k)
         Shard &s = ctx->shards[0];
         if (!ctx->p2p_ready) return fail(ctx, CGX_ERR_P2P, "cgx_p2p_import has not been called");
         const unsigned long long epoch = ++ctx->p2p_epoch[1];
+        hipEvent_t u0, u1;
+        CGX_TRY(take_update_events(ctx, &u0, &u1));
         HIP_TRY(ctx, cgx::launch_update_xr_p2p(ctx->n, s.rows, s.row0, s.p[(k + 1) & 1], s.apv, ctx->npart, ctx->mv, 1, epoch,
                                                s.x, s.rv, s.sc, k & 1, ctx->p2p_timeout_ticks, ctx->d_p2p_err, st,
-                                               s.plan.split > 1 ? s.ap_parts : s.Ap(), s.plan.split, ctx->seg_Sr));
+                                               s.plan.split > 1 ? s.ap_parts : s.Ap(), s.plan.split, ctx->seg_Sr, u0, u1));
         return CGX_OK;
     }
     // every other multi-rank consumer: K1's column pieces added up into the Ap slice of the segment, one p.Ap partial per
@@ -225,9 +253,12 @@ cgx_status enqueue_iteration(cgx_ctx *ctx, int k)
                                                 s.p[(k + 1) & 1] + s.row0, s.Ap(), s.tail(), s.sc, st));
     CGX_TRY(gather_segments(ctx, true));                                                             // cg.cc:106
     const bool folded = ctx->cfg.comm_mode == CGX_COMM_P2P;   // the exchange kernel already folded each rank's partials
-    for (auto &s : ctx->shards)
+    for (auto &s : ctx->shards) {
+        hipEvent_t u0 = nullptr, u1 = nullptr;
+        if (&s == &ctx->shards[0]) CGX_TRY(take_update_events(ctx, &u0, &u1));
         HIP_TRY(ctx, cgx::launch_update_xr(ctx->n, s.rows, s.row0, s.p[(k + 1) & 1], s.apv, folded ? ctx->npart : 0,
-                                           folded ? 1 : ctx->npart, s.x, s.rv, s.sc, k & 1, s.partials, st));   // cg.cc:105-116
+                                           folded ? 1 : ctx->npart, s.x, s.rv, s.sc, k & 1, s.partials, st, u0, u1));   // cg.cc:105-116
+    }
     return CGX_OK;
 }
 
@@ -388,7 +419,7 @@ cgx_status cgx_solve_end(cgx_ctx *ctx, double *x, cgx_result *res)
     if (x && ctx->h_stage) HIP_TRY(ctx, cgx::launch_copy_doubles(ctx->h_stage, s0.p[0], ctx->n, st));   // writes the pinned buffer
     else if (x) HIP_TRY(ctx, hipMemcpyAsync(x, s0.p[0], (size_t)ctx->n * sizeof(double), hipMemcpyDeviceToHost, st));
     HIP_TRY(ctx, hipStreamSynchronize(st));
-    if (ctx->ev_used || ctx->steps_ev_pending) CGX_TRY(harvest_gemv_events(ctx));
+    if (ctx->ev_used || ctx->upd_used || ctx->steps_ev_pending) CGX_TRY(harvest_gemv_events(ctx));
     if (x && x_dst != x) memcpy(x, x_dst, (size_t)ctx->n * sizeof(double));
     if (ctx->cfg.comm_mode == CGX_COMM_SELF)
         for (int v = 0; v < cgx::kSlots; ++v) hg[v] = hs.local[v];
@@ -431,12 +462,24 @@ cgx_status cgx_solve_end(cgx_ctx *ctx, double *x, cgx_result *res)
 cgx_status cgx_get_gemv_samples(cgx_ctx *ctx, double *ms_out, int cap, int *count)
 {
     if (!ctx || !count || (cap > 0 && !ms_out)) return CGX_ERR_BAD_ARG;
-    if (ctx->ev_used || ctx->steps_ev_pending) {
+    if (ctx->ev_used || ctx->upd_used || ctx->steps_ev_pending) {
         if (hipSetDevice(ctx->device) != hipSuccess) return CGX_ERR_HIP;
         CGX_TRY(harvest_gemv_events(ctx));
     }
     *count = (int)ctx->gemv_samples.size();
     for (int i = 0; i < cap && i < *count; ++i) ms_out[i] = ctx->gemv_samples[(size_t)i];
+    return CGX_OK;
+}
+
+cgx_status cgx_get_update_samples(cgx_ctx *ctx, double *ms_out, int cap, int *count)
+{
+    if (!ctx || !count || (cap > 0 && !ms_out)) return CGX_ERR_BAD_ARG;
+    if (ctx->ev_used || ctx->upd_used || ctx->steps_ev_pending) {
+        if (hipSetDevice(ctx->device) != hipSuccess) return CGX_ERR_HIP;
+        CGX_TRY(harvest_gemv_events(ctx));
+    }
+    *count = (int)ctx->upd_samples.size();
+    for (int i = 0; i < cap && i < *count; ++i) ms_out[i] = ctx->upd_samples[(size_t)i];
     return CGX_OK;
 }
 

@@ -79,7 +79,10 @@ typedef struct cgx_config {
     int  profile_gemv;        /* n > 0 = bracket every n-th K1 launch with HIP events (at most 2048 per cgx_solve_steps call);
                                  the FIRST launch of a cgx_solve_steps call starts on a drained stream and is never
                                  a sample unless profile_first is set (its event pair also spans the host's launch latency) */
-    int  reserved0;           /* (was: hipGraph replay; not needed, the host is never the bottleneck of this loop) */
+    int  profile_update;      /* 1 = the update kernel of an iteration (K3, or K3 with the exchange inside) is event-timed as well,
+                                 on the same launches as K1 (needs profile_gemv > 0): on a multi-GPU run its duration holds the
+                                 wait for the peers, i.e. the cost of the exchange (cgx_get_update_samples).  Default 0: a
+                                 timed dispatch costs ~5 us of stream time.  (The field was reserved0 before round 3.) */
     int  p2p_mailbox_kib;     /* CGX_COMM_P2P: mailbox size in KiB (0 = 4096)               */
     int  p2p_timeout_ms;      /* CGX_COMM_P2P: bound of every in-kernel wait (0 = 5000)     */
     int  p2p_separate_exchange; /* CGX_COMM_P2P: 1 = exchange in its own kernel between K1 and K3 (default 0: folded into K3) */
@@ -193,6 +196,10 @@ cgx_status  cgx_solve_end(cgx_ctx *ctx, double *x, cgx_result *res);
 /* The individual K1 durations (ms, HIP events on the library's stream) of the most recent cgx_solve_steps call, in
  * launch order: at most `cap` are written, *count receives how many exist.  bench.py reports their median. */
 cgx_status  cgx_get_gemv_samples(cgx_ctx *ctx, double *ms_out, int cap, int *count);
+
+/* The same for the update kernel (cfg.profile_update): K3 `k_update_xr`, or, under CGX_COMM_P2P with the exchange folded in,
+ * `k_update_xr_p2p`, whose duration includes the bounded wait for every peer's chunks (cg.cc:106,135-136). */
+cgx_status  cgx_get_update_samples(cgx_ctx *ctx, double *ms_out, int cap, int *count);
 
 /* ---- kernel probes (parity tests of the individual hot ops through the C ABI) ------------- */
 /* Ap = A_shard * p  (K1; cblas_dgemv at cg.cc:101-102) for every local shard; y receives the n

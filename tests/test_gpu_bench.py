@@ -73,6 +73,7 @@ def test_bench_short_window_statistics(gpu_pkg, oracle):
     c = d["config"]
     assert c["transport"] == "self" and c["ranks_seen"] == 1 and c["distinct_gpus"] == 1 and c["rccl_nranks"] is None
     assert c["k1_plan"]["variant"] == 1 and c["k1_plan"]["split"] == 1 and c["k1_plan"]["grid"] == n // c["k1_plan"]["R"]
+    assert "update_kernel" not in d          # one GPU: K3 is not event-timed unless asked (--profile-update)
 
 
 def test_bench_rccl_one_rank_under_the_launcher(gpu_pkg, oracle):
@@ -105,6 +106,10 @@ def test_bench_two_ranks_over_the_mailboxes(gpu_pkg, oracle):
     assert [q["rank"] for q in d["k1_per_rank"]] == [0, 1] and [q["rows"] for q in d["k1_per_rank"]] == [2048, 2048]
     assert d["k1_slowest_rank"] in (0, 1)
     assert all(q["min_ms"] <= q["median_ms"] <= q["max_ms"] for q in d["k1_per_rank"])
+    # the update kernel of the timed iterations (on several ranks: the kernel that holds the wait for the peers)
+    uk = d["update_kernel"]
+    assert ("k_update_xr_p2p" in uk["kernel"]) == (c["transport"] == "p2p") and [q["rank"] for q in uk["per_rank"]] == [0, 1]
+    assert all(q["launches_timed"] >= 10 and 0 < q["min_ms"] <= q["median_ms"] <= q["max_ms"] < d["ms_per_step"] for q in uk["per_rank"])
     _, ro = oracle.solve_lap2d(n, 35, 0.0, 2)
     assert abs(d["residual_after_run"] - ro["residual_prev"]) <= 1e-6 * ro["residual_prev"]
 
@@ -224,3 +229,15 @@ def test_bench_self_launch_refuses_more_ranks_than_gpus(gpu_pkg):
     d = one_line(r.stdout)
     assert r.returncode != 0 and d["value"] is None and d["n_gpus"] == 2
     assert "needs 2 MI355X, 1 visible" in d["error"]["message"]
+
+
+def test_bench_update_kernel_timing_on_request(gpu_pkg):
+    """--profile-update on one GPU: K3 of every iteration whose K1 is timed gets its own event pair; K1 + K3 stay below the step."""
+    r = subprocess.run([sys.executable, BENCH, "--steps", "20", "--warmup", "5", "--matrix-size", "8192", "--no-cpu-baseline",
+                        "--no-solve-window", "--profile-update"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = one_line(r.stdout)
+    u = d["update_kernel"]["per_rank"][0]
+    assert d["update_kernel"]["kernel"].startswith("k_update_xr (K3)") and u["launches_timed"] == 19
+    assert 0 < u["min_ms"] <= u["median_ms"] <= u["max_ms"]
+    assert d["roofline"]["median_launch_ms"] + u["median_ms"] <= d["ms_per_step"] and d["roofline"]["consistency"] == "ok"
