@@ -92,8 +92,12 @@ private:
             }
             if (cv_.wait_until(lk, deadline_) == std::cv_status::timeout && armed_ && !quit_ &&
                 std::chrono::steady_clock::now() >= deadline_) {
-                std::cerr << "cgsolver (rank " << rank_ << "): wire-up stage '" << stage_ << "' did not finish within " << seconds_
-                          << " s; giving up" << std::endl;
+                // one write: the ranks expire together and share stderr, piecewise output would interleave
+                std::ostringstream msg;
+                msg << "cgsolver (rank " << rank_ << "): wire-up stage '" << stage_ << "' did not finish within " << seconds_
+                    << " s; giving up\n";
+                const std::string text = msg.str();
+                if (write(2, text.data(), text.size()) < 0) {}
                 if (kids_)   // rank 0: end the other ranks and reap them, so that nothing of the job is left behind
                     for (pid_t k : *kids_) {
                         kill(k, SIGKILL);
