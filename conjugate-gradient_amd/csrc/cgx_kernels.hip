@@ -308,13 +308,15 @@ __global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 
     int ncols = ncols_all;
     int c_first = 0;
     if (split > 1) {
-        constexpr int kTrip = U * WAVES * 128;
-        const int trips = (ncols_all + kTrip - 1) / kTrip;
-        const int per = (trips + split - 1) / split;
-        c_first = piece * per * kTrip;
-        const long hi = (long)(piece + 1) * per * kTrip;
-        ncols = hi < ncols_all ? (int)hi : ncols_all;
-        if (c_first > ncols) c_first = ncols;
+        // Pieces are balanced to one 128-column unit (one wave's 1-KiB load): with whole trips of 1024 columns per piece the
+        // last piece of N = 46340 had 4 trips against 6 for the others, and since a piece IS an XCD here, that XCD sat idle
+        // for a third of the launch (311.5 us for the 5792 x 46340 shard, 0.862 of peak, against 0.896 at N = 32768).
+        const int units = (ncols_all + 127) / 128;
+        const int base = units / split, rem = units - base * split;
+        const int u0 = piece * base + (piece < rem ? piece : rem);
+        const int u1 = u0 + base + (piece < rem ? 1 : 0);
+        c_first = u0 * 128;
+        ncols = u1 * 128 < ncols_all ? u1 * 128 : ncols_all;
         Ap += (long)piece * ap_stride;
     }
     // ncols = n rounded up to even: the pad columns up to the pitch hold zeros in A and in the vectors and are skipped
@@ -337,9 +339,11 @@ __global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 
 
     constexpr int kStep = WAVES * 128;   // doubles swept by the workgroup per step
     int c = c_first + w * 128 + lane * 2;
-    int step = c_first / kStep;          // index of the step this trip starts with
-    // next step whose p_new this workgroup stores: step st belongs to the row group st mod groups (of the piece that
-    // sweeps it), so every step is stored exactly once
+    // index of the 512-column block (of the whole row) this WAVE's 128 columns lie in; it advances by one per step.  A piece
+    // need not start on a block boundary, so the waves of a workgroup may be in different blocks.
+    int step = (c_first + w * 128) / kStep;
+    // next block whose p_new this workgroup stores: block b belongs to the row group b mod groups (the wave of that group
+    // which sweeps a 128-column unit of it stores that unit), so every column is stored exactly once
     int my_step = group;
     if (my_step < step) my_step += ((step - my_step + groups - 1) / groups) * groups;
     double beta = 0.0;
