@@ -52,9 +52,10 @@ def parse_args():
     ap.add_argument("--matrix-size", dest="n", type=int, default=0, help="matrix size (default 32768; weak mode: floor(16384*sqrt(P)))")
     ap.add_argument("--mode", choices=["strong", "weak"], default="strong")
     ap.add_argument("--variant", type=int, default=0, help="K1 shape override (DESIGN.md)")
-    ap.add_argument("--transport", choices=["auto", "p2p", "p2p-sep", "rccl"], default="auto",
-                    help="multi-GPU exchange: direct xGMI mailboxes with the exchange folded into K3 (p2p) or as its own "
-                         "kernel (p2p-sep), RCCL, or whichever of those works and calibrates fastest on this node (auto)")
+    ap.add_argument("--transport", choices=["auto", "p2p-tag", "p2p", "p2p-sep", "rccl"], default="auto",
+                    help="multi-GPU exchange: direct xGMI mailboxes with the exchange folded into K3 -- bytes handed over as "
+                         "tagged 8-byte words (p2p-tag) or as payload + flag words (p2p) -- or as its own kernel (p2p-sep), RCCL, "
+                         "or whichever of those works and calibrates fastest on this node (auto)")
     ap.add_argument("--lda-pad", type=int, default=-1)
     ap.add_argument("--cpu-baseline-iters", type=int, default=20)   # 20-50 loop bodies at N=32768, not 500
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -292,7 +293,7 @@ class Bench:
             self.profile_every = (1 if world == 1 else 2) if args.steps <= 64 else (4 if world == 1 else 8)
 
     def make_solver(self, transport):
-        """transport: 'self' | 'rccl' | 'p2p' | 'p2p-sep'.  Returns a ready solver or None (same answer on every rank).
+        """transport: 'self' | 'rccl' | 'p2p-tag' | 'p2p' | 'p2p-sep'.  Returns a ready solver or None (same answer on every rank).
         The wire-up is cut into stages; after each one all ranks agree (all_ok) whether to go on, so that a failure on
         one rank can never leave the others inside a different torch.distributed call.  Every stage that can block on a
         peer is bounded by --wireup-timeout."""
@@ -347,7 +348,8 @@ class Bench:
                 return give_up()
         else:
             def create():
-                box["s"] = pkg.CGSolver(comm_mode=pkg.COMM_P2P, p2p_separate_exchange=(transport == "p2p-sep"), **common)
+                box["s"] = pkg.CGSolver(comm_mode=pkg.COMM_P2P, p2p_separate_exchange=(transport == "p2p-sep"),
+                                        p2p_tagged=(transport == "p2p-tag"), **common)
                 box["handle"] = box["s"].p2p_export()
             if not stage("mailbox allocation", create):
                 return give_up()
@@ -481,7 +483,7 @@ class Bench:
         if not self.use_comm:
             order = ["self"]
         elif args.transport == "auto":
-            order = ["p2p", "p2p-sep", "rccl"]
+            order = ["p2p-tag", "p2p", "p2p-sep", "rccl"]
         else:
             order = [args.transport]
         # Build every candidate transport that works on this node; with more than one, a short calibration run
@@ -595,6 +597,8 @@ class Bench:
             "rows_per_gpu": rows0,
             "collectives": {"self": "none",
                             "rccl": "1 x ncclAllGather per iteration ([Ap slice | p.Ap partials])",
+                            "p2p-tag": "1 exchange per iteration over IPC/xGMI mailboxes, folded into K3, tagged 8-byte words, no flags "
+                                       "or fences ([Ap slice | p.Ap partial per chunk])",
                             "p2p": "1 exchange per iteration over IPC/xGMI mailboxes, folded into K3 ([Ap slice | p.Ap])",
                             "p2p-sep": "1 mailbox all-gather kernel per iteration over IPC/xGMI ([Ap slice | p.Ap])"}[transport],
             "transport": transport,
@@ -620,7 +624,8 @@ class Bench:
             # the update kernel of the same iterations whose K1 was timed: K3, or (p2p) K3 with the exchange inside, whose
             # duration holds the bounded wait for every peer's chunks -- what the exchange costs each rank (cg.cc:106,135-136)
             line["update_kernel"] = {
-                "kernel": "k_update_xr_p2p (K3 with the exchange inside)" if transport == "p2p" else "k_update_xr (K3)",
+                "kernel": {"p2p": "k_update_xr_p2p (K3 with the exchange inside)",
+                           "p2p-tag": "k_update_xr_p2p_tagged (K3 with the exchange inside, tagged words)"}.get(transport, "k_update_xr (K3)"),
                 "timing": "HIP events bound to the dispatch, the launches whose K1 was timed",
                 "per_rank": [{"rank": q, "launches_timed": int(u[0]), "min_ms": u[1], "median_ms": u[2], "max_ms": u[3]}
                              for q, u in enumerate(upd_rows)],

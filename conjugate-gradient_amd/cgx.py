@@ -39,7 +39,7 @@ class Config(C.Structure):
         ("lda_pad", C.c_int), ("check_every", C.c_int), ("profile_gemv", C.c_int), ("profile_update", C.c_int),
         ("p2p_mailbox_kib", C.c_int), ("p2p_timeout_ms", C.c_int), ("p2p_separate_exchange", C.c_int),
         ("matrix_format", C.c_int), ("profile_first", C.c_int), ("profile_markers", C.c_int),
-        ("p2p_no_acquire_fence", C.c_int), ("reserved", C.c_int * 1),
+        ("p2p_no_acquire_fence", C.c_int), ("p2p_tagged", C.c_int),
     ]
 
 
@@ -161,7 +161,7 @@ class CGSolver:
     def __init__(self, comm_mode=COMM_SELF, nranks=1, rank=0, device=0, unique_id=None, gemv_variant=0,
                  lda_pad=-1, check_every=0, profile_gemv=False, p2p_timeout_ms=0, p2p_mailbox_kib=0,
                  p2p_separate_exchange=False, matrix_format=MATRIX_DENSE, profile_first=False,
-                 profile_markers=False, p2p_no_acquire_fence=False, profile_update=False):
+                 profile_markers=False, p2p_no_acquire_fence=False, profile_update=False, p2p_tagged=False):
         L = lib()
         cfg = Config()
         L.cgx_config_init(C.byref(cfg))
@@ -181,6 +181,7 @@ class CGSolver:
         cfg.profile_first = 1 if profile_first else 0
         cfg.profile_markers = 1 if profile_markers else 0
         cfg.p2p_no_acquire_fence = 1 if p2p_no_acquire_fence else 0
+        cfg.p2p_tagged = 1 if p2p_tagged else 0
         if unique_id is not None:
             assert len(unique_id) == UNIQUE_ID_BYTES
             C.memmove(cfg.unique_id, bytes(unique_id), UNIQUE_ID_BYTES)

@@ -157,7 +157,7 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
         // The update kernel with the exchange inside works one row per thread and its workgroups wait for each other inside
         // the kernel: all of them must be resident at once, and their flags must fit the mailbox's flag words.
         int limit = 0;
-        HIP_TRY(ctx, cgx::update_xr_p2p_resident_limit(ctx->device, &limit));
+        HIP_TRY(ctx, cgx::update_xr_p2p_resident_limit(ctx->device, ctx->mv.tagged != 0, &limit));
         if (ctx->resident_limit > 0) limit = ctx->resident_limit;
         const long grid = ((long)n + 255) / 256;
         if (grid > cgx::kMaxVectorGrid || grid > limit || (long)ctx->nranks * cpr > cgx::kMaxChunkFlags)
@@ -176,7 +176,9 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
         // it only after every peer has pushed its channel-2 data, i.e. after every peer is done with channel 1.
         // (Chunk flag words change their meaning with cpr, but only ever hold epochs of the past: a stale word can
         // never satisfy a wait for a newer epoch.)
-        const long slot[cgx::kP2pChannels] = {16, ((long)(ctx->seg_Sr + ctx->npart + 1) * 8 + 15) / 16 * 16, (long)cgx::kSlots * 8};
+        // (tagged words: every double of the fused exchange travels as two 8-byte words)
+        const long slot[cgx::kP2pChannels] = {16, ((long)(ctx->seg_Sr + ctx->npart + 1) * (ctx->mv.tagged ? 16 : 8) + 15) / 16 * 16,
+                                              (long)cgx::kSlots * 8};
         long off = p2p_fixed_prefix(ctx->nranks);
         ctx->mv.cflag_off = p2p_flag_bytes();
         ctx->mv.data_off[0] = p2p_data0_off();
@@ -402,6 +404,7 @@ cgx_status cgx_create(cgx_ctx **out, const cgx_config *cfg_in)
         ctx->mv.nranks = cfg.nranks;
         ctx->mv.rank = cfg.rank;
         ctx->mv.acquire = cfg.p2p_no_acquire_fence ? 0 : 1;
+        ctx->mv.tagged = (cfg.p2p_tagged && !ctx->cfg.p2p_separate_exchange) ? 1 : 0;
         ctx->mv.base[cfg.rank] = ctx->mailbox;
         // the fixed part of the layout (flag words, chunk flag words, the two small channels) never depends on the problem
         ctx->mv.cflag_off = p2p_flag_bytes();
@@ -537,7 +540,7 @@ cgx_status cgx_p2p_selftest(cgx_ctx *ctx, int rounds, int *ok)
         const int rows = (me == P - 1) ? n - me * n_loc : n_loc, row0 = me * n_loc;
         const int Sr = (n - (P - 1) * n_loc + 1) / 2 * 2, cpr = cgx::chunks_per_rank(Sr);
         const int grid = cgx::update_xr_grid(n);
-        ctx->mv.slot_bytes[1] = ((long)(Sr + cpr + 1) * 8 + 15) / 16 * 16;
+        ctx->mv.slot_bytes[1] = ((long)(Sr + cpr + 1) * (ctx->mv.tagged ? 16 : 8) + 15) / 16 * 16;
         if ((size_t)(ctx->mv.data_off[1] + 2L * P * ctx->mv.slot_bytes[1]) > ctx->mailbox_bytes || P * cpr > cgx::kMaxChunkFlags)
             return fail(ctx, CGX_ERR_P2P, "mailbox too small for the self-test");
         cgx::SegView apv{nullptr, Sr + cpr + 1, Sr, n_loc, P, n, me, 0, 0, 0};

@@ -178,6 +178,8 @@ struct MailboxView {
     long data_off[kP2pChannels];         // byte offset of channel c's data area
     long slot_bytes[kP2pChannels];       // bytes per (parity, rank) slot
     int nranks, rank;
+    int tagged;                          // 1 = the fused update hands its bytes over as tagged words (no flags, no fences;
+                                         // cgx_kernels.hip "Tagged words"); slots of channel 1 are then twice as large
     int acquire;                         // 1 = one system-scope acquire fence per workgroup behind the flag wait of
                                          // k_update_xr_p2p (default); 0 only for the A/B of its cost (tools/p2p_one_rank.py)
 };
@@ -209,7 +211,7 @@ hipError_t launch_chunk_exchange_selftest(int n, int rows, int row0, const doubl
                                           hipStream_t s);
 // Workgroups of k_update_xr_p2p the device keeps resident at once (occupancy x CUs): its grid must not exceed this, since
 // its workgroups wait for each other inside the kernel.
-hipError_t update_xr_p2p_resident_limit(int device, int *workgroups);
+hipError_t update_xr_p2p_resident_limit(int device, bool tagged, int *workgroups);
 
 // Loopback "collective": copy local[kSlots] of every shard into gathered[] of every shard (<= 16 shards).
 hipError_t launch_loopback_gather(double *const *gathered_ptrs, const Scalars *const *scalar_ptrs, int nshards,

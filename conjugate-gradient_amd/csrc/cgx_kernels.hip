@@ -1462,6 +1462,124 @@ __global__ __launch_bounds__(256) void k_update_xr_p2p(int n, int rows, int row0
     if (tid == 0) r[rv.Sr + blockIdx.x] = rr;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tagged words: the exchange without flags and without fences (cfg.p2p_tagged; the transport self-test decides whether a
+// node may use it).  Every double travels as two 8-byte words {32 bits of the value | 32 bits of the epoch}, each written
+// with ONE relaxed system-scope atomic store and read with relaxed system-scope atomic loads.  A reader that sees the
+// epoch in a word knows that the word's other half belongs to the same store (8-byte atomics are single-copy atomic), and
+// it needs nothing else: no word depends on the order in which any other word arrives, so there is no release, no flag,
+// no acquire, and no barrier between "the data is there" and "use it" -- the chain is store -> (xGMI) -> the poll that
+// hits.  A slot still holds the words of epoch e-2 until they are overwritten: the tag is compared for equality.  The
+// mailbox is zero-filled when it is created; no tag of the first 4.29e9 epochs is 0.
+// Twice the bytes on the wire (64 KiB per rank at N = 32768): irrelevant for a latency-bound exchange.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tagged_store(unsigned long long *dst, double v, unsigned tag)
+{
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v), t = (unsigned long long)tag << 32;
+    __hip_atomic_store(dst, (bits & 0xffffffffull) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(dst + 1, (bits >> 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// polls both words until they carry `tag` (bounded by the wall clock); *ok = 0 if the wait expired
+__device__ __forceinline__ double tagged_load(const unsigned long long *src, unsigned tag, long long timeout_ticks, int *err, int *ok)
+{
+    const long long t0 = wall_clock64();
+    unsigned long long w0, w1;
+    for (;;) {
+        w0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        w1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - t0 > timeout_ticks) {
+            *ok = 0;
+            atomicExch(err, 1);
+            break;
+        }
+    }
+    return __longlong_as_double((long long)((w0 & 0xffffffffull) | (w1 << 32)));
+}
+
+__device__ __forceinline__ unsigned long long *tagged_slot(const MailboxView &mv, int owner, int chan, unsigned long long epoch, int q)
+{
+    return reinterpret_cast<unsigned long long *>(mv.base[owner] + mv.data_off[chan] +
+                                                  ((long)(epoch & 1) * mv.nranks + q) * mv.slot_bytes[chan]);
+}
+
+// The tagged-word form of k_update_xr_p2p: same pairs, same chunk arithmetic (chunk_pair / chunk_dot: the same bits), same
+// fold order of the partials; only how the bytes are handed over differs.
+template <bool SELFTEST>
+__global__ __launch_bounds__(256) void k_update_xr_p2p_tagged(int n, int rows, int row0, const double *__restrict__ p_new,
+                                                               SegView apv, int cpr, MailboxView mv, int chan,
+                                                               unsigned long long epoch, double *__restrict__ x, SegView rv,
+                                                               Scalars *sc, int parity_rs, long long timeout_ticks, int *err,
+                                                               const double *__restrict__ ap_src, int split, long part_stride,
+                                                               double *__restrict__ vals, double *__restrict__ sums)
+{
+    __shared__ double lds[4];
+    const int tid = threadIdx.x, P = mv.nranks, me = mv.rank;
+    // The tag is the epoch's low 32 bits, XORed with the upper half of a quiet NaN: a bijection (two epochs collide only 2^32
+    // apart, and a position is rewritten every second epoch), and for the first 2^19 epochs of a context no finite double
+    // that another kernel may have left in the slot (the mailbox all-gather of the set-up phases stores plain doubles
+    // there) can look like a tagged word of the current epoch.
+    const unsigned tag = (unsigned)epoch ^ 0xFFF80000u;
+    int done = 0;
+    double rsold = 0.0, r_i = 0.0, p_i = 0.0, x_i = 0.0;
+    const int had_err = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int i = blockIdx.x * 256 + tid;   // global row
+    const int li = i - row0;
+    const bool in = i < n, own = in && li >= 0 && li < rows;
+    if constexpr (!SELFTEST) {
+        done = sc->done;
+        rsold = sc->rs[parity_rs];
+        if (in) r_i = rv.base[i];
+        if (own) { p_i = p_new[i]; x_i = x[li]; }
+    }
+    const int npairs = P * cpr;
+    int pr = blockIdx.x;
+    ChunkItem it{};
+    if (pr < npairs) it = chunk_fetch(pr, cpr, ap_src, split, part_stride, apv.Sr, p_new + row0, rows);
+    if (__syncthreads_or(done | had_err)) return;
+    while (pr < npairs) {
+        const double d = chunk_dot<4>(it.pp, it.a, lds);
+        unsigned long long *out = tagged_slot(mv, it.peer, chan, epoch, me);
+        if (it.row < apv.Sr) {
+            tagged_store(out + 2 * it.row, it.a.x, tag);
+            tagged_store(out + 2 * it.row + 2, it.a.y, tag);
+        }
+        if (tid == 0) tagged_store(out + 2 * (apv.Sr + it.c), d, tag);
+        pr += gridDim.x;
+        if (pr < npairs) it = chunk_fetch(pr, cpr, ap_src, split, part_stride, apv.Sr, p_new + row0, rows);
+    }
+    int ok = 1;
+    double cs = 0.0;
+    for (int f = tid; f < npairs; f += 256) {                        // all ranks' chunk partials, one fixed order
+        const int q = f / cpr, c = f - q * cpr;
+        cs += tagged_load(tagged_slot(mv, me, chan, epoch, q) + 2 * (apv.Sr + c), tag, timeout_ticks, err, &ok);
+    }
+    double ap_i = 0.0;
+    if (in) {
+        const int q = (P > 1) ? seg_owner(apv, i) : 0;
+        ap_i = tagged_load(tagged_slot(mv, me, chan, epoch, q) + 2 * (i - q * apv.n_loc), tag, timeout_ticks, err, &ok);
+    }
+    if (!__syncthreads_and(ok)) return;
+    const double conj = block_sum<4>(cs, lds);                       // bit-identical on every rank (cg.cc:106)
+    if constexpr (SELFTEST) {
+        if (in) vals[i] = ap_i;
+        if (tid == 0) sums[blockIdx.x] = conj;
+    } else {
+        const double alpha = safeguarded_alpha(rsold, conj);         // cg.cc:107
+        double rr = 0.0;
+        if (in) {
+            const double rn = fma(-alpha, ap_i, r_i);                 // cg.cc:113
+            rv.base[i] = rn;
+            rr = rn * rn;                                             // cg.cc:116
+        }
+        if (own) x[li] = fma(alpha, p_i, x_i);                        // cg.cc:110
+        rr = block_sum<4>(rr, lds);
+        if (tid == 0) rv.base[rv.Sr + blockIdx.x] = rr;
+    }
+}
+
 // The exchange of k_update_xr_p2p alone, on a pattern: every thread stores the Ap element it read for its row to
 // vals[i], every workgroup the folded partials to sums[blockIdx.x].  cgx_p2p_selftest compares both with what every rank
 // must have sent.
@@ -1857,6 +1975,12 @@ hipError_t launch_update_xr_p2p(int n, int rows, int row0, const double *p_new, 
 {
     if (cpr != chunks_per_rank(apv.Sr) || (long)mv.nranks * cpr > kMaxChunkFlags || split < 1 || split > kMaxSplit)
         return hipErrorInvalidValue;
+    if (mv.tagged) {
+        hipExtLaunchKernelGGL((k_update_xr_p2p_tagged<false>), dim3(update_xr_grid(n)), dim3(256), 0, s, e0, e1, 0, n, rows, row0, p_new,
+                              apv, cpr, mv, chan, epoch, x, rv, sc, parity, timeout_ticks, err, ap_src, split, stride,
+                              (double *)nullptr, (double *)nullptr);
+        return hipGetLastError();
+    }
     hipExtLaunchKernelGGL(k_update_xr_p2p, dim3(update_xr_grid(n)), dim3(256), 0, s, e0, e1, 0, n, rows, row0, p_new, apv, cpr, mv,
                           chan, epoch, x, rv, sc, parity, timeout_ticks, err, ap_src, split, stride);
     return hipGetLastError();
@@ -1869,15 +1993,22 @@ hipError_t launch_chunk_exchange_selftest(int n, int rows, int row0, const doubl
 {
     if (cpr != chunks_per_rank(apv.Sr) || (long)mv.nranks * cpr > kMaxChunkFlags || split < 1 || split > kMaxSplit)
         return hipErrorInvalidValue;
+    if (mv.tagged) {
+        hipLaunchKernelGGL((k_update_xr_p2p_tagged<true>), dim3(update_xr_grid(n)), dim3(256), 0, s, n, rows, row0, p_like, apv, cpr, mv,
+                           chan, epoch, (double *)nullptr, SegView{}, (Scalars *)nullptr, 0, timeout_ticks, err, ap_src, split, stride,
+                           vals, sums);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(k_chunk_exchange_selftest, dim3(update_xr_grid(n)), dim3(256), 0, s, n, rows, row0, p_like, apv, cpr, mv,
                        chan, epoch, timeout_ticks, err, ap_src, split, stride, vals, sums);
     return hipGetLastError();
 }
 
-hipError_t update_xr_p2p_resident_limit(int device, int *workgroups)
+hipError_t update_xr_p2p_resident_limit(int device, bool tagged, int *workgroups)
 {
     int per_cu = 0, cus = 0;
-    hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_update_xr_p2p, 256, 0);
+    hipError_t e = tagged ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_update_xr_p2p_tagged<false>, 256, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_update_xr_p2p, 256, 0);
     if (e != hipSuccess) return e;
     e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
     if (e != hipSuccess) return e;

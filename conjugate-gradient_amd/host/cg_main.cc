@@ -125,7 +125,8 @@ int usage(const char *prog)
               << "       " << prog << " FILE.mtx NUM_THREADS BLOCK_WIDTH true|false OUTFILE\n"
               << "       " << prog << " FILE.mtx OUTFILE [MAXITER]       (matrix file, MPI-form output)\n"
               << "options: --gpus P (or CG_NGPU=P)  one process per MI355X\n"
-              << "         --transport auto|p2p|rccl  exchange: direct xGMI mailboxes, RCCL, or p2p with RCCL fallback\n"
+              << "         --transport auto|p2p-tag|p2p|rccl  exchange: direct xGMI mailboxes (bytes handed over as tagged words, or\n"
+              << "                                  as payload + flag words), RCCL, or the first of those whose self-test passes\n"
               << "         --wireup-timeout S       seconds any one stage of the multi-GPU wire-up may take (default 120, or\n"
               << "                                  CG_WIREUP_TIMEOUT); a stage that does not come back ends the job with exit code 1\n"
               << "         --loopback P             P logical row blocks on one GPU\n"
@@ -307,41 +308,50 @@ int main(int argc, char **argv)
                 if (!all_min(dev_ok)) throw std::runtime_error("--gpus " + std::to_string(ngpu) + ": not every rank has a usable MI355X");
             });
             bool have = false;
-            if (transport != "rccl") {
-                // direct-xGMI mailboxes: create, exchange IPC handles, self-test; all ranks agree on the outcome
+            // direct-xGMI mailboxes: create, exchange IPC handles, self-test; all ranks agree on the outcome.  Two forms of
+            // the per-iteration exchange, each with its own device code in the self-test: tagged 8-byte words (no flags, no
+            // fences) first, payload + flag words second; RCCL if neither works between these devices.
+            std::vector<std::string> forms;
+            if (transport == "auto") forms = {"p2p-tag", "p2p"};
+            else if (transport == "p2p-tag" || transport == "p2p") forms = {transport};
+            else if (transport != "rccl") throw std::runtime_error("--transport must be auto, p2p-tag, p2p or rccl");
+            for (const std::string &form : forms) {
                 cfg.comm_mode = CGX_COMM_P2P;
+                cfg.p2p_tagged = form == "p2p-tag" ? 1 : 0;
                 int ok = 1;
                 std::vector<unsigned char> all;
-                stage("mailbox allocation", [&] {
+                stage("mailbox allocation (" + form + ")", [&] {
                     unsigned char handle[CGX_IPC_HANDLE_BYTES] = {0};
                     try {
                         holder.reset(new CGSolver(cfg));
                         if (cgx_p2p_export(holder->context(), handle) != CGX_OK) ok = 0;
                     } catch (const std::exception &e) {
-                        std::cerr << "cgsolver (rank " << rank << "): p2p unavailable: " << e.what() << std::endl;
+                        std::cerr << "cgsolver (rank " << rank << "): " << form << " unavailable: " << e.what() << std::endl;
                         ok = 0;
                     }
                     all = allgather_bytes(handle, CGX_IPC_HANDLE_BYTES);
                     ok = all_min(ok);
                 });
                 if (ok) {
-                    stage("opening the peers' mailboxes", [&] {
+                    stage("opening the peers' mailboxes (" + form + ")", [&] {
                         if (cgx_p2p_import(holder->context(), all.data()) != CGX_OK) ok = 0;
                         ok = all_min(ok);
                     });
                     if (ok)
-                        stage("mailbox self-test", [&] {
+                        stage("mailbox self-test (" + form + ")", [&] {
                             int st_ok = 0;
                             if (cgx_p2p_selftest(holder->context(), 32, &st_ok) != CGX_OK) st_ok = 0;
                             have = all_min(st_ok) != 0;
                         });
                 }
-                if (!have) {
-                    holder.reset();
-                    if (transport == "p2p") throw std::runtime_error("--transport p2p: mailboxes unavailable or self-test failed");
-                    if (rank == 0) std::cerr << "cgsolver: direct peer exchange unavailable, using RCCL" << std::endl;
-                }
+                if (have) break;
+                holder.reset();
+                if (rank == 0) std::cerr << "cgsolver: direct peer exchange (" << form << ") unavailable" << std::endl;
             }
+            if (!have && (transport == "p2p" || transport == "p2p-tag"))
+                throw std::runtime_error("--transport " + transport + ": mailboxes unavailable or self-test failed");
+            if (!have && !forms.empty() && rank == 0) std::cerr << "cgsolver: using RCCL" << std::endl;
+            cfg.p2p_tagged = 0;
             if (!have) {
                 cfg.comm_mode = CGX_COMM_RCCL;
                 stage("ncclCommInitRank", [&] {

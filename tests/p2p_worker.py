@@ -1,6 +1,6 @@
 """Worker for tests/test_gpu_p2p.py: one OS process per rank, all on ONE GPU, exchanging through the
 CGX_COMM_P2P mailboxes (hipIpc) -- the direct-xGMI transport rehearsed without a multi-GPU node.
-Control plane (handle exchange, verdict) over gloo.  argv: n max_iter out.json [variant] [separate_exchange 0|1]"""
+Control plane (handle exchange, verdict) over gloo.  argv: n max_iter out.json [variant] [separate_exchange 0|1] [tagged 0|1]"""
 import json
 import os
 import sys
@@ -18,12 +18,13 @@ def main():
     n, max_iter, out_path = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
     variant = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     separate = len(sys.argv) > 5 and sys.argv[5] == "1"
+    tagged = len(sys.argv) > 6 and sys.argv[6] == "1"
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     assert torch.cuda.is_available()
     pkg = g.load_package()
     s = pkg.CGSolver(comm_mode=pkg.COMM_P2P, nranks=world, rank=rank, device=0, gemv_variant=variant, p2p_timeout_ms=20000,
-                     p2p_separate_exchange=separate)
+                     p2p_separate_exchange=separate, p2p_tagged=tagged)
     mine = torch.tensor(list(s.p2p_export()), dtype=torch.uint8)
     allh = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(allh, mine)

@@ -100,7 +100,8 @@ def test_bench_two_ranks_over_the_mailboxes(gpu_pkg, oracle):
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
     d = one_line(r.stdout)
     c = d["config"]
-    assert d["n_gpus"] == 2 and c["transport"] in ("p2p", "p2p-sep") and c["ranks_seen"] == 2
+    assert d["n_gpus"] == 2 and c["transport"] in ("p2p-tag", "p2p", "p2p-sep") and c["ranks_seen"] == 2
+    assert set(c["transport_calibration_ms_per_iteration"]) == {"p2p-tag", "p2p", "p2p-sep"}
     assert c["transport_ranks_wired"] == [2, 2] and c["distinct_gpus"] == 1 and c["process_group_ranks"] == 2
     assert any("rccl" in note for note in c["transport_notes"])
     assert [q["rank"] for q in d["k1_per_rank"]] == [0, 1] and [q["rows"] for q in d["k1_per_rank"]] == [2048, 2048]
@@ -108,7 +109,7 @@ def test_bench_two_ranks_over_the_mailboxes(gpu_pkg, oracle):
     assert all(q["min_ms"] <= q["median_ms"] <= q["max_ms"] for q in d["k1_per_rank"])
     # the update kernel of the timed iterations (on several ranks: the kernel that holds the wait for the peers)
     uk = d["update_kernel"]
-    assert ("k_update_xr_p2p" in uk["kernel"]) == (c["transport"] == "p2p") and [q["rank"] for q in uk["per_rank"]] == [0, 1]
+    assert ("k_update_xr_p2p" in uk["kernel"]) == (c["transport"] in ("p2p", "p2p-tag")) and [q["rank"] for q in uk["per_rank"]] == [0, 1]
     assert all(q["launches_timed"] >= 10 and 0 < q["min_ms"] <= q["median_ms"] <= q["max_ms"] < d["ms_per_step"] for q in uk["per_rank"])
     _, ro = oracle.solve_lap2d(n, 35, 0.0, 2)
     assert abs(d["residual_after_run"] - ro["residual_prev"]) <= 1e-6 * ro["residual_prev"]
@@ -141,8 +142,8 @@ def test_bench_auto_transport_one_rank_under_the_launcher(gpu_pkg):
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
     d = one_line(r.stdout)
     c = d["config"]
-    assert set(c["transport_calibration_ms_per_iteration"]) == {"p2p", "p2p-sep", "rccl"}
-    assert c["transport"] in ("p2p", "p2p-sep", "rccl") and c["transport_notes"] is None
+    assert set(c["transport_calibration_ms_per_iteration"]) == {"p2p-tag", "p2p", "p2p-sep", "rccl"}
+    assert c["transport"] in ("p2p-tag", "p2p", "p2p-sep", "rccl") and c["transport_notes"] is None
     assert c["transport"] == min(c["transport_calibration_ms_per_iteration"], key=c["transport_calibration_ms_per_iteration"].get)
     assert c["rccl_nranks"] == 1          # from the RCCL candidate of the calibration, whichever transport carried the run
     assert d["value"] > 0 and d["roofline"]["consistency"] == "ok" and d["roofline"]["launches_timed"] == 19
@@ -175,8 +176,8 @@ def test_bench_survives_a_wireup_stage_that_never_returns(gpu_pkg):
                  env={"CGX_BENCH_TEST_HANG": "rccl:ncclCommInitRank"}, timeout=300)
     d = one_line(r.stdout)
     c = d["config"]
-    assert d["value"] > 0 and c["transport"] in ("p2p", "p2p-sep")
-    assert set(c["transport_calibration_ms_per_iteration"]) == {"p2p", "p2p-sep"}
+    assert d["value"] > 0 and c["transport"] in ("p2p-tag", "p2p", "p2p-sep")
+    assert set(c["transport_calibration_ms_per_iteration"]) == {"p2p-tag", "p2p", "p2p-sep"}
     assert any("rccl" in note and "did not finish within 3 s" in note for note in c["transport_notes"])
     assert r.returncode == 0, r.stderr[-2000:]
 
@@ -211,7 +212,7 @@ def test_bench_self_launch_two_ranks(gpu_pkg, oracle):
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
     d = one_line(r.stdout)
     c = d["config"]
-    assert d["n_gpus"] == 2 and c["ranks_seen"] == 2 and c["process_group_ranks"] == 2 and c["transport"] in ("p2p", "p2p-sep")
+    assert d["n_gpus"] == 2 and c["ranks_seen"] == 2 and c["process_group_ranks"] == 2 and c["transport"] in ("p2p-tag", "p2p", "p2p-sep")
     assert d["value"] > 0 and d["iterations_done"] == 35 and len(c["k1_plan"]) == 2 and "cpu_baseline" in d
     _, ro = oracle.solve_lap2d(n, 35, 0.0, 2)
     assert abs(d["residual_after_run"] - ro["residual_prev"]) <= 1e-6 * ro["residual_prev"]

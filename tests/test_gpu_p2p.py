@@ -12,11 +12,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run(world, n, max_iter, tmp_path, port, variant=0, separate=0):
+def run(world, n, max_iter, tmp_path, port, variant=0, separate=0, tagged=0):
     out = tmp_path / ("p2p_%d_%d.json" % (world, n))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "tests", "p2p_worker.py"), str(n), str(max_iter), str(out), str(variant), str(separate)]
+           os.path.join(ROOT, "tests", "p2p_worker.py"), str(n), str(max_iter), str(out), str(variant), str(separate), str(tagged)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=420,
                        env=dict(os.environ, OMP_NUM_THREADS="1", MASTER_ADDR="127.0.0.1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -30,6 +30,18 @@ def run(world, n, max_iter, tmp_path, port, variant=0, separate=0):
 ])
 def test_p2p_processes_on_one_gpu(tmp_path, world, n, max_iter, port, separate):
     v = run(world, n, max_iter, tmp_path, port, separate=separate)
+    _check_p2p(v, n)
+
+
+@pytest.mark.parametrize("world,n,max_iter,port,variant", [
+    (2, 2048, 200, 29731, 0), (4, 1000, 150, 29732, 0), (3, 1024, 4000, 29733, 0), (3, 5, 3, 29734, 0),
+    (3, 1000, 150, 29735, 10823), (4, 4096, 100, 29736, 10445), (2, 6000, 60, 29737, 0),   # column pieces; six chunks per rank
+])
+def test_p2p_tagged_words_processes_on_one_gpu(tmp_path, world, n, max_iter, port, variant):
+    """The fused exchange with its bytes handed over as tagged 8-byte words (no flags, no fences: cgx_config.p2p_tagged) --
+    the same chunks, the same arithmetic, the same bits as the flag form; real processes over IPC, incl. a second solve of
+    another size on the same contexts, empty shards, and a K1 whose Ap arrives as column pieces."""
+    v = run(world, n, max_iter, tmp_path, port, variant=variant, tagged=1)
     _check_p2p(v, n)
 
 
@@ -56,34 +68,41 @@ def _check_p2p(v, n):
         assert v["residual_rel"] < 1e-6, v
 
 
-def test_cgsolver_cli_forked_ranks_over_mailboxes(tmp_path):
+@pytest.mark.parametrize("transport", ["p2p", "p2p-tag", "auto"])
+def test_cgsolver_cli_forked_ranks_over_mailboxes(tmp_path, transport):
     """`cgsolver N OUT MAXITER --gpus 3`: the CLI forks one process per rank before touching the GPU and wires
-    the mailboxes over pipes.  --same-device puts every rank on device 0 (one-GPU rehearsal)."""
+    the mailboxes over pipes.  --same-device puts every rank on device 0 (one-GPU rehearsal).  auto = the tagged-word form
+    if its self-test passes on every rank, else the flag form, else RCCL."""
     exe = os.path.join(ROOT, "conjugate-gradient_amd", "cgsolver")
     out = tmp_path / "strong.txt"
-    r = subprocess.run([exe, "2048", str(out), "200", "--gpus", "3", "--same-device", "--transport", "p2p", "--stats"],
+    r = subprocess.run([exe, "2048", str(out), "200", "--gpus", "3", "--same-device", "--transport", transport, "--stats"],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "[STEP 200] residual = 1.331819e-05, ||x|| = 8.808702e+07" in r.stdout      # reference's own numbers (SURVEY section 4)
     assert r.stdout.count("[STEP") == 1                                                 # only rank 0 prints (cg.cc:144)
     assert out.read_text().strip().startswith("2048,3,")
-    assert "gpus=3" in r.stderr
+    assert "gpus=3" in r.stderr and "unavailable" not in r.stderr
 
 
-def test_p2p_config4_n32768_500_iterations_4_processes(tmp_path):
+@pytest.mark.parametrize("tagged,port", [(0, 29706), (1, 29738)])
+def test_p2p_config4_n32768_500_iterations_4_processes(tmp_path, tagged, port):
     """BASELINE.json configs[3] shape (N=32768, 500 iterations, row blocks) with 4 real processes exchanging over
-    the mailboxes, against the reference's recorded residual, ||x|| and sampled x."""
-    v = run(4, 32768, 500, tmp_path, 29706)
+    the mailboxes (both forms of the fused exchange), against the reference's recorded residual, ||x|| and sampled x."""
+    v = run(4, 32768, 500, tmp_path, port, tagged=tagged)
     assert v["selftest_ok"] and v["ranks_agree"], v
     assert v["k"] == 500 and not v["converged"], v
     assert v["residual_rel"] < 1e-6 and v["x_norm_rel"] < 1e-12 and v["dx"] < 1e-12, v
 
 
-def test_p2p_wait_is_bounded(tmp_path):
-    """A peer that never answers must produce CGX_ERR_P2P after the timeout, not a hang."""
+@pytest.mark.parametrize("tagged,late,port", [(0, 0, 29707), (0, 1, 29739), (1, 1, 29740)])
+def test_p2p_wait_is_bounded(tmp_path, tagged, late, port):
+    """A peer that never answers must produce CGX_ERR_P2P after the timeout, not a hang: in the set-up phase (mailbox
+    all-gather kernel), and -- `late` -- in the middle of the iteration loop, where the wait sits inside the fused update
+    kernel (flag words, or tagged words polled by every thread)."""
     out = tmp_path / "stall.json"
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29707", os.path.join(ROOT, "tests", "p2p_stall_worker.py"), str(out)]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "p2p_stall_worker.py"), str(out),
+           str(tagged), str(late)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=120,
                        env=dict(os.environ, OMP_NUM_THREADS="1", MASTER_ADDR="127.0.0.1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]

@@ -8,7 +8,9 @@ pkg = g.load_package()
 n = int(os.environ.get("N", "32768")); P = int(os.environ.get("SHARDS", "8")); v = int(os.environ.get("VARIANT", "0"))
 mode = os.environ.get("MODE", "loopback")
 if mode == "p2p":
-    s = pkg.CGSolver(comm_mode=pkg.COMM_P2P, nranks=1, rank=0, gemv_variant=v, profile_gemv=int(os.environ.get("PROFILE", "0")))
+    s = pkg.CGSolver(comm_mode=pkg.COMM_P2P, nranks=1, rank=0, gemv_variant=v, profile_gemv=int(os.environ.get("PROFILE", "0")),
+                     p2p_tagged=os.environ.get("TAGGED", "0") == "1")
+    assert s.p2p_selftest(8)
 else:
     s = pkg.CGSolver(comm_mode=pkg.COMM_LOOPBACK if P > 1 else pkg.COMM_SELF, nranks=P, gemv_variant=v, profile_gemv=int(os.environ.get("PROFILE", "0")))
 s.generate_lap2d_matrix(n); s.set_max_iter(10**6); s.tolerance(0.0); s.init_source_term(1.0 / n)

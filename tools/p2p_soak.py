@@ -1,6 +1,6 @@
 """Soak of the direct peer exchange: WORLD processes on one GPU, tol = 0, many thousands of exchanges back to back; after
 every chunk all ranks must hold bit-identical x and scalars.  (dev tool; launch with torch.distributed.run)
-argv: n total_iterations chunk [separate 0|1]"""
+argv: n total_iterations chunk [separate 0|1] [tagged 0|1]"""
 import os, sys, time
 import numpy as np, torch
 import torch.distributed as dist
@@ -9,10 +9,11 @@ import __graft_entry__ as g
 
 n, total, chunk = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 separate = len(sys.argv) > 4 and sys.argv[4] == "1"
+tagged = len(sys.argv) > 5 and sys.argv[5] == "1"
 dist.init_process_group(backend="gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 pkg = g.load_package()
-s = pkg.CGSolver(comm_mode=pkg.COMM_P2P, nranks=world, rank=rank, device=0, p2p_timeout_ms=20000, p2p_separate_exchange=separate)
+s = pkg.CGSolver(comm_mode=pkg.COMM_P2P, nranks=world, rank=rank, device=0, p2p_timeout_ms=20000, p2p_separate_exchange=separate, p2p_tagged=tagged)
 mine = torch.tensor(list(s.p2p_export()), dtype=torch.uint8)
 allh = [torch.zeros_like(mine) for _ in range(world)]
 dist.all_gather(allh, mine)

@@ -13,4 +13,6 @@ export MASTER_ADDR=127.0.0.1 OMP_NUM_THREADS=1
 run 300 $TR --nproc-per-node 4 --master-port 29801 $R/tools/p2p_soak.py 4096 1000000 2000 0
 run 300 $TR --nproc-per-node 3 --master-port 29802 $R/tools/p2p_soak.py 8192 300000 1500 0
 run 300 $TR --nproc-per-node 4 --master-port 29803 $R/tools/p2p_soak.py 4096 300000 2000 1
+run 300 $TR --nproc-per-node 4 --master-port 29804 $R/tools/p2p_soak.py 4096 1000000 2000 0 1
+run 300 $TR --nproc-per-node 3 --master-port 29805 $R/tools/p2p_soak.py 8192 300000 1500 0 1
 grep -E "^###|done|rc=|no leak|MISMATCH|DISAGREE|Error|error" $OUT | tail -40
