@@ -1443,12 +1443,14 @@ __global__ __launch_bounds__(256) void k_update_xr_p2p(int n, int rows, int row0
     }
     const int ok = chunk_wait_all(mv, epoch, npairs, timeout_ticks, err);
     if (!__syncthreads_and(ok)) return;
-    const double cs = chunk_read_partials(mv, chan, epoch, cpr, apv.Sr, npairs);
+    // the row's Ap element first, the partials behind it: both loads are in flight together (the other way round the
+    // partial is consumed -- waited for -- before the Ap load is even issued: one more memory round trip for wave 0)
     double ap_i = 0.0;
     if (in) {
         const int q = (P > 1) ? seg_owner(apv, i) : 0;
         ap_i = chunk_read_ap(mv, chan, epoch, q, i - q * apv.n_loc);
     }
+    const double cs = chunk_read_partials(mv, chan, epoch, cpr, apv.Sr, npairs);
     const double conj = block_sum<4>(cs, lds);                       // bit-identical on every rank (cg.cc:106)
     const double alpha = safeguarded_alpha(rsold, conj);             // cg.cc:107
     double rr = 0.0;
@@ -1550,16 +1552,50 @@ __global__ __launch_bounds__(256) void k_update_xr_p2p_tagged(int n, int rows, i
         pr += gridDim.x;
         if (pr < npairs) it = chunk_fetch(pr, cpr, ap_src, split, part_stride, apv.Sr, p_new + row0, rows);
     }
+    // Every thread polls the two words of its own Ap element and -- the first P*cpr threads -- of one chunk partial, both in
+    // the same loop: all four loads of a round are in flight together (one after the other, the first wave of every
+    // workgroup paid two memory round trips where one does).
     int ok = 1;
-    double cs = 0.0;
-    for (int f = tid; f < npairs; f += 256) {                        // all ranks' chunk partials, one fixed order
-        const int q = f / cpr, c = f - q * cpr;
-        cs += tagged_load(tagged_slot(mv, me, chan, epoch, q) + 2 * (apv.Sr + c), tag, timeout_ticks, err, &ok);
-    }
-    double ap_i = 0.0;
-    if (in) {
-        const int q = (P > 1) ? seg_owner(apv, i) : 0;
-        ap_i = tagged_load(tagged_slot(mv, me, chan, epoch, q) + 2 * (i - q * apv.n_loc), tag, timeout_ticks, err, &ok);
+    double cs = 0.0, ap_i = 0.0;
+    {
+        const unsigned long long *wa = nullptr, *wp = nullptr;
+        if (in) {
+            const int q = (P > 1) ? seg_owner(apv, i) : 0;
+            wa = tagged_slot(mv, me, chan, epoch, q) + 2 * (i - q * apv.n_loc);
+        }
+        if (tid < npairs) {
+            const int q = tid / cpr, c = tid - q * cpr;
+            wp = tagged_slot(mv, me, chan, epoch, q) + 2 * (apv.Sr + c);
+        }
+        const unsigned long long *dummy = tagged_slot(mv, me, chan, epoch, 0);   // a mapped address for the loads nobody needs
+        bool need_a = wa != nullptr, need_p = wp != nullptr;
+        const long long t0 = wall_clock64();
+        while (need_a || need_p) {
+            const unsigned long long *pa = need_a ? wa : dummy, *pp = need_p ? wp : dummy;
+            const unsigned long long a0 = __hip_atomic_load(pa, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long a1 = __hip_atomic_load(pa + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long p0 = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            const unsigned long long p1 = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (need_a && (unsigned)(a0 >> 32) == tag && (unsigned)(a1 >> 32) == tag) {
+                ap_i = __longlong_as_double((long long)((a0 & 0xffffffffull) | (a1 << 32)));
+                need_a = false;
+            }
+            if (need_p && (unsigned)(p0 >> 32) == tag && (unsigned)(p1 >> 32) == tag) {
+                cs = __longlong_as_double((long long)((p0 & 0xffffffffull) | (p1 << 32)));
+                need_p = false;
+            }
+            if (!(need_a || need_p)) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > timeout_ticks) {               // bounded: give up, tell the host
+                ok = 0;
+                atomicExch(err, 1);
+                break;
+            }
+        }
+        for (int f = tid + 256; f < npairs; f += 256) {              // more than 256 partials (n > 131072): the rest, same order
+            const int q = f / cpr, c = f - q * cpr;
+            cs += tagged_load(tagged_slot(mv, me, chan, epoch, q) + 2 * (apv.Sr + c), tag, timeout_ticks, err, &ok);
+        }
     }
     if (!__syncthreads_and(ok)) return;
     const double conj = block_sum<4>(cs, lds);                       // bit-identical on every rank (cg.cc:106)
