@@ -56,7 +56,8 @@ struct GemvPlan {
                      // pitch are zero in A and in every vector and are never touched
     int split;       // variant 1, fused launches only: column pieces per row group (1 = none).  grid counts ALL workgroups
                      // (row groups x split) = the number of p.Ap partials; a plain launch uses grid / split
-    int light;       // variant 1: the one-round form (grid <= 512 workgroups, at most two per CU; see k_gemv_colsplit)
+    int light;       // variant 1: the one-round form (first trip issued ahead of the iteration head, 256 registers to spend;
+                     // see k_gemv_colsplit); variant 3: the LDS-window form of K1b
 };
 
 // Choose the K1 shape for a shard of `rows` x `n` held at pitch `lda` (variant 0 = default).  allow_split: the consumer of

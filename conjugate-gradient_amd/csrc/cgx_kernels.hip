@@ -10,10 +10,13 @@
 //                                           rsold = rsnew                        cg.cc:132
 //                   head of iteration k:    Ap_sub = A_sub p                     cg.cc:100-102 (cblas_dgemv)
 //                                           partials of p_sub.Ap_sub             cg.cc:105     (cblas_ddot)
+//   [several ranks: Kp prefold_ap           the column pieces of K1's Ap added up; one p_sub.Ap_sub partial per
+//                                           512-row chunk of the slice ("Chunks" below)          cg.cc:105]
 //   -- exchange: all-gather of [Ap slice | p.Ap partials]                        cg.cc:106 (MPI_Allreduce) + 135-136
 //   K3 update_xr    p.Ap = fixed-order sum of all ranks' partials; alpha         cg.cc:107
 //                   x_sub += alpha p_sub                                         cg.cc:110
 //                   r -= alpha Ap for ALL n rows (r is replicated); r.r          cg.cc:113,116
+//   [CGX_COMM_P2P: Kp, the exchange and K3 are ONE kernel, k_update_xr_p2p (flag words) / k_update_xr_p2p_tagged]
 //
 // What travels between ranks is Ap, not p: r and p are replicated, every rank updates the whole r from the
 // gathered Ap and reduces r.r over all n rows in the same fixed order, so r.r is bit-identical on every

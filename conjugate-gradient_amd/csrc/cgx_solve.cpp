@@ -7,7 +7,8 @@
 //     enqueues kernels and polls one int every `check_every` iterations, so the stream never drains;
 //   * after convergence every kernel of the remaining enqueued iterations exits at its first
 //     instruction, which reproduces the reference's `break` (cg.cc:120-121) exactly;
-//   * one iteration = two kernels (K1 fused GEMV, K3 x/r update) and ONE exchange: an in-place all-gather of
+//   * one iteration = two kernels (K1 fused GEMV, K3 x/r update; on several ranks a small prefold kernel in front of
+//     the exchange, or -- CGX_COMM_P2P -- all of that inside K3) and ONE exchange: an in-place all-gather of
 //     equal segments [Ap slice | p.Ap partials] replaces MPI_Allreduce(p.Ap), MPI_Allreduce(r.r) and
 //     MPI_Allgatherv(p): r and p are replicated, every rank updates all of r from the gathered Ap, reduces r.r
 //     over all n rows in one fixed order (bit-identical everywhere) and forms p = r + beta p inside the next K1.

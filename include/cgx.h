@@ -50,7 +50,8 @@ typedef enum cgx_comm_mode {
     CGX_COMM_RCCL = 2,        /* this process is shard `rank` of `nranks`, RCCL over xGMI   */
     CGX_COMM_P2P = 3          /* same process model, but the one exchange per iteration stores straight into the
                                  peers' IPC-mapped mailboxes over xGMI, folded into the update kernel (no RCCL at
-                                 all); needs cgx_p2p_export / cgx_p2p_import after cgx_create                 */
+                                 all); needs cgx_p2p_export / cgx_p2p_import after cgx_create; two forms of handing the
+                                 bytes over: payload + flag words (default), or tagged words (cgx_config.p2p_tagged)   */
 } cgx_comm_mode;
 
 /* How the row block is held on the device.  DENSE is the reference's contract (Matrix, code/MPI/matrix.hh:7-29:
