@@ -62,7 +62,7 @@ def parse_args():
     ap.add_argument("--no-profile-gemv", action="store_true", help="do not time K1 with HIP events")
     ap.add_argument("--profile-every", type=int, default=0,
                     help="event-time every n-th K1 launch (default: when steps <= 64 every launch on one GPU, so that a "
-                         "short window still gives >= 16 samples, every 2nd on several; else 4 on one GPU, 8 on several)")
+                         "short window still gives >= 16 samples, every 4th on several; else 4 on one GPU, 8 on several)")
     ap.add_argument("--profile-update", action="store_true",
                     help="also event-time the update kernel (K3, or K3 with the exchange inside) on the launches whose K1 is timed; "
                          "default: on for several GPUs (its duration then holds the wait for the peers = the cost of the exchange), "
@@ -288,9 +288,11 @@ class Bench:
         elif args.profile_every:
             self.profile_every = args.profile_every
         else:
-            # a timed dispatch costs ~5 us of stream time (measured): every launch on one GPU's 1.2 ms iteration,
-            # every second one where the iteration is a fraction of that
-            self.profile_every = (1 if world == 1 else 2) if args.steps <= 64 else (4 if world == 1 else 8)
+            # a timed dispatch costs ~4.5 us of stream time (measured, tools/window_short.sh: a 181 us iteration -- what a
+            # rank of an 8-GPU run has -- slows by 2.6 % with every K1 timed, 5.6 % with the update kernel timed as well,
+            # 0.3 % with every 4th): every launch on one GPU's 1.2 ms iteration, every 4th one (plus the update kernel of the
+            # same iterations) where the iteration is a fraction of that
+            self.profile_every = (1 if world == 1 else 4) if args.steps <= 64 else (4 if world == 1 else 8)
 
     def make_solver(self, transport):
         """transport: 'self' | 'rccl' | 'p2p-tag' | 'p2p' | 'p2p-sep'.  Returns a ready solver or None (same answer on every rank).

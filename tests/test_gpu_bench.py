@@ -110,7 +110,7 @@ def test_bench_two_ranks_over_the_mailboxes(gpu_pkg, oracle):
     # the update kernel of the timed iterations (on several ranks: the kernel that holds the wait for the peers)
     uk = d["update_kernel"]
     assert ("k_update_xr_p2p" in uk["kernel"]) == (c["transport"] in ("p2p", "p2p-tag")) and [q["rank"] for q in uk["per_rank"]] == [0, 1]
-    assert all(q["launches_timed"] >= 10 and 0 < q["min_ms"] <= q["median_ms"] <= q["max_ms"] < d["ms_per_step"] for q in uk["per_rank"])
+    assert all(q["launches_timed"] >= 5 and 0 < q["min_ms"] <= q["median_ms"] <= q["max_ms"] < d["ms_per_step"] for q in uk["per_rank"])
     _, ro = oracle.solve_lap2d(n, 35, 0.0, 2)
     assert abs(d["residual_after_run"] - ro["residual_prev"]) <= 1e-6 * ro["residual_prev"]
 
@@ -160,7 +160,7 @@ def test_bench_four_ranks_uneven_partition(gpu_pkg, oracle):
     assert d["n_gpus"] == 4 and c["ranks_seen"] == 4 and c["transport_ranks_wired"] == [4, 4, 4, 4] and c["distinct_gpus"] == 1
     assert [q["rows"] for q in d["k1_per_rank"]] == [2500, 2500, 2500, 2501]
     assert [q["bytes_per_launch"] for q in d["k1_per_rank"]] == [8.0 * (rows * n + n + rows) for rows in (2500, 2500, 2500, 2501)]
-    assert all(q["launches_timed"] >= 10 and q["launches_discarded"] == 1 for q in d["k1_per_rank"])     # every 2nd of 24
+    assert all(q["launches_timed"] >= 5 and q["launches_discarded"] == 1 for q in d["k1_per_rank"])     # every 4th of 24
     rf = d["roofline"]
     assert rf["rank"] in (0, 1, 2, 3) and rf["bytes_per_launch"] == d["k1_per_rank"][rf["rank"]]["bytes_per_launch"]
     assert rf["achieved"] == min(q["GBs"] for q in d["k1_per_rank"])
