@@ -163,7 +163,8 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
         if (grid > cgx::kMaxVectorGrid || grid > limit || (long)ctx->nranks * cpr > cgx::kMaxChunkFlags)
             return fail(ctx, CGX_ERR_UNSUPPORTED,
                         "CGX_COMM_P2P with the exchange folded into the update kernel: " + std::to_string(grid) + " workgroups (one row "
-                        "per thread) must be resident at once, the device keeps " + std::to_string(std::min(limit, cgx::kMaxVectorGrid)) +
+                        "per thread) must be resident at once; the device keeps " + std::to_string(limit) + " of this kernel resident "
+                        "(occupancy x CUs), the kernel takes at most " + std::to_string(cgx::kMaxVectorGrid) +
                         "; use p2p_separate_exchange or CGX_COMM_RCCL");
     } else if (ctx->cfg.comm_mode == CGX_COMM_P2P && n > 256 * cgx::kMaxVectorGrid) {
         return fail(ctx, CGX_ERR_UNSUPPORTED, "CGX_COMM_P2P handles at most 262144 rows; use CGX_COMM_RCCL");
