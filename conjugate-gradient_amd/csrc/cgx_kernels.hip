@@ -1478,11 +1478,16 @@ __global__ __launch_bounds__(256) void k_update_xr_p2p(int n, int rows, int row0
 // mailbox is zero-filled when it is created; no tag of the first 4.29e9 epochs is 0.
 // Twice the bytes on the wire (64 KiB per rank at N = 32768): irrelevant for a latency-bound exchange.
 // ------------------------------------------------------------------------------------------------
+// Both words of one double leave as ONE 16-byte store with the system-scope write-through bits (what the two relaxed 8-byte
+// atomic stores of the definition compile to, `global_store_dwordx2 ... sc0 sc1`, as one instruction and one request: over
+// xGMI a request is a packet, and 8-byte packets cost 2.7x the time per byte of 16-byte ones, measured for sc1 stores in the
+// guide).  Nothing depends on the two words arriving together: each validates itself.
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void tagged_store(unsigned long long *dst, double v, unsigned tag)
 {
-    const unsigned long long bits = (unsigned long long)__double_as_longlong(v), t = (unsigned long long)tag << 32;
-    __hip_atomic_store(dst, (bits & 0xffffffffull) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __hip_atomic_store(dst + 1, (bits >> 32) | t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    const u4 w = {(unsigned)bits, tag, (unsigned)(bits >> 32), tag};   // little endian: {lo32 | tag<<32}, {hi32 | tag<<32}
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(dst), "v"(w) : "memory");
 }
 
 // polls both words until they carry `tag` (bounded by the wall clock); *ok = 0 if the wait expired
@@ -1547,9 +1552,17 @@ __global__ __launch_bounds__(256) void k_update_xr_p2p_tagged(int n, int rows, i
     while (pr < npairs) {
         const double d = chunk_dot<4>(it.pp, it.a, lds);
         unsigned long long *out = tagged_slot(mv, it.peer, chan, epoch, me);
-        if (it.row < apv.Sr) {
-            tagged_store(out + 2 * it.row, it.a.x, tag);
-            tagged_store(out + 2 * it.row + 2, it.a.y, tag);
+        {
+            // A lane holds the pair of rows (2L, 2L+1) of its wave's 128 rows; transposed through the wave so that one store
+            // instruction covers 64 consecutive elements = 1 KiB without holes (whole 64-byte requests instead of half-masked
+            // ones): lane L stores element L, then element 64 + L.
+            const int lane = tid & 63, src = lane >> 1;
+            const bool odd = (lane & 1) != 0;
+            const double x1 = __shfl(it.a.x, src, 64), y1 = __shfl(it.a.y, src, 64);
+            const double x2 = __shfl(it.a.x, 32 + src, 64), y2 = __shfl(it.a.y, 32 + src, 64);
+            const int row_a = it.row - 2 * lane + lane, row_b = row_a + 64;
+            if (row_a < apv.Sr) tagged_store(out + 2 * row_a, odd ? y1 : x1, tag);
+            if (row_b < apv.Sr) tagged_store(out + 2 * row_b, odd ? y2 : x2, tag);
         }
         if (tid == 0) tagged_store(out + 2 * (apv.Sr + it.c), d, tag);
         pr += gridDim.x;
