@@ -174,3 +174,14 @@ int main() { std::printf("%d\n", (int)std::is_polymorphic<CGSolver>::value); ret
     assert r.returncode == 0, r.stderr
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0 and r.stdout.strip() == "1"
+
+
+def test_build_does_not_load_the_library_into_the_calling_process():
+    """__graft_entry__.build() checks that libcgx.so loads -- in a child process.  Loaded into the caller, the library binds
+    the process to /opt/rocm's HIP runtime before torch brings its own, and a smoke() in the same process then finds no
+    device (seen on the GPU box: `python -c "import __graft_entry__ as g; g.build(); g.smoke()"`)."""
+    code = ("import __graft_entry__ as g; g.build(); "
+            "print('MAPPED' if any('libcgx' in l for l in open('/proc/self/maps')) else 'CLEAN')")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.strip().endswith("CLEAN")
