@@ -7,6 +7,7 @@ Reference interface mirrored: class CGSolver, code/MPI/cg.hh:11-57 and code/CUDA
 import ctypes as C
 import os
 import subprocess
+import sys
 
 import numpy as np
 
@@ -80,6 +81,14 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise OSError("libcgx.so not built (run `make -C conjugate-gradient_amd` or __graft_entry__.build()); "
                           "the product path has no CPU fallback")
+        # torch first, if it is there: libcgx then binds to the one HIP / RCCL runtime torch ships instead of bringing
+        # /opt/rocm's as a second one into the process -- with two, whichever comes second may see no device (seen on the GPU
+        # box when the library had been loaded before torch).  CGX_NO_TORCH=1 keeps torch out (the no-torch dev tools).
+        if "torch" not in sys.modules and os.environ.get("CGX_NO_TORCH") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:   # noqa: BLE001 -- a box without torch: /opt/rocm's runtime alone is fine
+                pass
         L = C.CDLL(LIB_PATH)
         dp = C.POINTER(C.c_double)
         ip = C.POINTER(C.c_int)

@@ -1,6 +1,7 @@
 """first_solve.py without torch in the process (what the cgsolver binary sees).  (dev tool)"""
 import os, sys, time, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["CGX_NO_TORCH"] = "1"   # keep torch out of the process (cgx.lib() would import it first)
 import __graft_entry__ as g
 pkg = g.load_package()
 for n in (2048, 4096, 8192):

@@ -1,6 +1,7 @@
 """begin / steps / end of the first and second solve of a process, without torch (dev tool)."""
 import os, sys, time, numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["CGX_NO_TORCH"] = "1"   # keep torch out of the process (cgx.lib() would import it first)
 import __graft_entry__ as g
 pkg = g.load_package()
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
