@@ -30,6 +30,7 @@ EXPORTS = [
     "cgx_get_update_samples",
     "cgx_probe_gemv", "cgx_probe_time_gemv", "cgx_probe_vector_ops", "cgx_probe_get_matrix_rows",
     "cgx_probe_get_source_term", "cgx_probe_set_fault_after", "cgx_probe_set_resident_limit",
+    "cgx_probe_parse_matrix_market",
 ]
 
 
@@ -130,6 +131,7 @@ def lib():
         L.cgx_probe_get_source_term.argtypes = [vp, C.c_int, dp]
         L.cgx_probe_set_fault_after.argtypes = [vp, C.c_int]
         L.cgx_probe_set_resident_limit.argtypes = [vp, C.c_int]
+        L.cgx_probe_parse_matrix_market.argtypes = [C.c_char_p, C.c_int, ip, ip, ip, ip, ip, ip, dp, C.c_long, C.c_char_p, C.c_int]
         for name in EXPORTS:
             fn = getattr(L, name)
             if fn.restype is C.c_int and name not in ("cgx_config_init",):
@@ -158,6 +160,25 @@ def comm_unique_id():
     if st:
         raise CgxError(st, lib().cgx_last_error(None).decode(errors="replace"))
     return bytes(buf)
+
+
+def parse_matrix_market(path, threads=0):
+    """The library's Matrix-Market parser alone (host only): (m, n, symmetric, I, J, a) with 0-based indices in file order."""
+    m, n, nz, sym = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+    err = C.create_string_buffer(512)
+    st = lib().cgx_probe_parse_matrix_market(os.fsencode(path), int(threads), C.byref(m), C.byref(n), C.byref(nz), C.byref(sym),
+                                             None, None, None, 0, err, 512)
+    if st:
+        raise CgxError(st, err.value.decode(errors="replace"))
+    I = np.zeros(nz.value, dtype=np.int32)
+    J = np.zeros(nz.value, dtype=np.int32)
+    a = np.zeros(nz.value, dtype=np.float64)
+    st = lib().cgx_probe_parse_matrix_market(os.fsencode(path), int(threads), C.byref(m), C.byref(n), C.byref(nz), C.byref(sym),
+                                             I.ctypes.data_as(C.POINTER(C.c_int)), J.ctypes.data_as(C.POINTER(C.c_int)), _dp(a),
+                                             nz.value, err, 512)
+    if st:
+        raise CgxError(st, err.value.decode(errors="replace"))
+    return m.value, n.value, bool(sym.value), I, J, a
 
 
 class CGSolver:

@@ -197,6 +197,16 @@ cgx_status setup_problem(cgx_ctx *ctx, int n);       // allocate the shards of a
 
 // cgx_matrix.cpp
 cgx_status alloc_dia(cgx_ctx *ctx, Shard &s, const std::vector<int> &offs);
+// A Matrix-Market coordinate file as MatrixCOO::read leaves it (matrix_coo.cc:7-60): sizes, symmetry, 0-based entries in
+// file order.  Host only; parsed on `nthreads` threads.
+struct MtxEntries {
+    int m = 0, n = 0, nz = 0;
+    bool sym = false;
+    std::vector<int> I, J;
+    std::vector<double> a;
+};
+cgx_status parse_matrix_market(const char *path, MtxEntries *out, std::string *err, int nthreads);
+int default_parse_threads();   // CGX_MTX_THREADS, else the host's hardware threads, at most 16
 
 // cgx_solve.cpp
 cgx_status p2p_allgather(cgx_ctx *ctx, int chan, const double *src, int count, double *dst, long dst_stride, int copy_self,

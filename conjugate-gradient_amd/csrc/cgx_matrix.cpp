@@ -3,6 +3,9 @@
 // for dense and for the opt-in banded storage.
 #include "cgx_internal.h"
 
+#include <sys/mman.h>
+#include <sys/stat.h>
+
 #include <algorithm>
 #include <cctype>
 #include <chrono>
@@ -10,7 +13,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <string>
+#include <thread>
 #include <vector>
 
 #ifndef M_PI
@@ -129,119 +134,248 @@ cgx_status cgx_set_matrix_dense(cgx_ctx *ctx, const double *A, long lda_host, in
     return CGX_OK;
 }
 
-// ---- MatrixCOO::read + Matrix::read, matrix_coo.cc:7-60 and matrix.cc:6-22 -------------------------
-cgx_status cgx_read_matrix(cgx_ctx *ctx, const char *path)
+// ---- MatrixCOO::read, matrix_coo.cc:7-60: the file as a list of entries, host only ---------------------
+}  // extern "C"
+
+namespace cgxi {
+
+namespace {
+
+inline bool is_ws(unsigned char c) { return c == ' ' || c == '\n' || c == '\t' || c == '\r' || c == '\v' || c == '\f'; }   // isspace, "C" locale
+
+// The bytes behind the header, mapped (regular file) or read (anything else).
+struct Body {
+    const char *p = nullptr;
+    size_t len = 0;
+    void *map = nullptr;
+    size_t map_len = 0;
+    std::vector<char> owned;
+    ~Body()
+    {
+        if (map) munmap(map, map_len);
+    }
+};
+
+// Entries "%d %d %lg" (matrix_coo.cc:48) = a stream of white-space separated tokens, three per entry.  The body is cut into
+// one range per thread; a token belongs to the range it STARTS in.  Pass 1 counts the tokens of every range, the prefix sum
+// tells every range the index of its first token -- and with it which field of which entry that is -- and pass 2 parses
+// every token straight into its slot (entry = index / 3, field = index % 3).  No carry between ranges, no order between
+// threads, the result is the file order.  Tokens are copied into a small terminated buffer before strtol / strtod, so the
+// mapping needs no terminator.  Returns "" or the message of the FIRST bad entry of the file.
+std::string parse_entries(const char *data, size_t len, long nz, int m, int n, int *I, int *J, double *a, int nthreads)
 {
-    if (!ctx || !path) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_read_matrix: bad argument");
+    if (nz <= 0) return "";
+    // at least 1 MiB per thread -- unless the caller forces a count (negative: the parser's own tests cut tiny files into
+    // many ranges so that range boundaries fall inside tokens and inside entries)
+    nthreads = nthreads < 0 ? std::min(-nthreads, (int)std::max<size_t>(len, 1)) : std::max(1, std::min(nthreads, (int)(len / (1 << 20)) + 1));
+    std::vector<size_t> start((size_t)nthreads + 1);
+    for (int t = 0; t <= nthreads; ++t) start[(size_t)t] = len * (size_t)t / (size_t)nthreads;
+    auto first_token = [&](size_t pos) {   // first position >= pos where a token starts
+        if (pos > 0 && pos < len && !is_ws((unsigned char)data[pos - 1]))
+            while (pos < len && !is_ws((unsigned char)data[pos])) ++pos;          // inside a token of the previous range
+        while (pos < len && is_ws((unsigned char)data[pos])) ++pos;
+        return pos;
+    };
+    std::vector<long> count((size_t)nthreads, 0);
+    auto in_threads = [&](const std::function<void(int)> &body) {
+        std::vector<std::thread> th;
+        for (int t = 1; t < nthreads; ++t) th.emplace_back(body, t);
+        body(0);
+        for (auto &x : th) x.join();
+    };
+    in_threads([&](int t) {
+        size_t pos = first_token(start[(size_t)t]);
+        const size_t end = start[(size_t)t + 1];
+        long c = 0;
+        while (pos < end) {                                                       // pos is the start of a token
+            ++c;
+            while (pos < len && !is_ws((unsigned char)data[pos])) ++pos;
+            while (pos < len && is_ws((unsigned char)data[pos])) ++pos;
+        }
+        count[(size_t)t] = c;
+    });
+    std::vector<long> tok0((size_t)nthreads + 1, 0);
+    for (int t = 0; t < nthreads; ++t) tok0[(size_t)t + 1] = tok0[(size_t)t] + count[(size_t)t];
+    const long want = 3 * nz;
+    std::vector<long> bad((size_t)nthreads, -1);                                  // first bad ENTRY per range, -1 = none
+    std::vector<int> kind((size_t)nthreads, 0);                                   // 1 = unreadable, 2 = index out of range
+    in_threads([&](int t) {
+        size_t pos = first_token(start[(size_t)t]);
+        const size_t end = start[(size_t)t + 1];
+        long k = tok0[(size_t)t];
+        char tmp[128];
+        while (pos < end && k < want) {
+            const size_t b = pos;
+            while (pos < len && !is_ws((unsigned char)data[pos])) ++pos;
+            const size_t tl = pos - b;
+            const long e = k / 3;
+            const int field = (int)(k - 3 * e);
+            bool ok = tl < sizeof tmp;
+            if (ok) {
+                memcpy(tmp, data + b, tl);
+                tmp[tl] = '\0';
+                char *endp = tmp;
+                if (field < 2) {
+                    const long v = strtol(tmp, &endp, 10);
+                    ok = endp == tmp + tl;
+                    if (ok && (v < 1 || v > (field == 0 ? (long)m : (long)n))) {  // 1-based in the file, matrix_coo.cc:49-50
+                        bad[(size_t)t] = e;
+                        kind[(size_t)t] = 2;
+                        return;
+                    }
+                    if (ok) (field == 0 ? I : J)[e] = (int)v - 1;
+                } else {
+                    const double v = strtod(tmp, &endp);
+                    ok = endp == tmp + tl;
+                    if (ok) a[e] = v;
+                }
+            }
+            if (!ok) {
+                bad[(size_t)t] = e;
+                kind[(size_t)t] = 1;
+                return;
+            }
+            ++k;
+            while (pos < len && is_ws((unsigned char)data[pos])) ++pos;
+        }
+    });
+    long first_bad = -1;
+    int first_kind = 0;
+    for (int t = 0; t < nthreads; ++t)
+        if (bad[(size_t)t] >= 0 && (first_bad < 0 || bad[(size_t)t] < first_bad)) {
+            first_bad = bad[(size_t)t];
+            first_kind = kind[(size_t)t];
+        }
+    if (first_bad < 0 && tok0[(size_t)nthreads] < want) {                         // the file ends inside entry tokens / 3
+        first_bad = tok0[(size_t)nthreads] / 3;
+        first_kind = 1;
+    }
+    if (first_bad < 0) return "";
+    return first_kind == 2 ? "Matrix Market index out of range" : "Matrix Market entry " + std::to_string(first_bad) + " unreadable";
+}
+
+}  // namespace
+
+// Header (mmio.c:96-179,189-217 as matrix_coo.cc:19-40 uses them) + entries.  err: CGX_ERR_IO / CGX_ERR_UNSUPPORTED text.
+cgx_status parse_matrix_market(const char *path, MtxEntries *out, std::string *err, int nthreads)
+{
     FILE *f = fopen(path, "r");
-    if (!f) return fail(ctx, CGX_ERR_IO, std::string("Could not open matrix: ") + path);   // matrix_coo.cc:14-17
+    if (!f) { *err = std::string("Could not open matrix: ") + path; return CGX_ERR_IO; }   // matrix_coo.cc:14-17
     struct Closer {
         FILE *f;
         ~Closer() { fclose(f); }
     } closer{f};
 
     char line[2048];
-    if (!fgets(line, sizeof line, f)) return fail(ctx, CGX_ERR_IO, "Could not process Matrix Market banner.");
+    if (!fgets(line, sizeof line, f)) { *err = "Could not process Matrix Market banner."; return CGX_ERR_IO; }
     char tok[5][64] = {{0}};
     if (sscanf(line, "%63s %63s %63s %63s %63s", tok[0], tok[1], tok[2], tok[3], tok[4]) != 5 ||
-        strcmp(tok[0], "%%MatrixMarket") != 0)
-        return fail(ctx, CGX_ERR_IO, "Could not process Matrix Market banner.");   // matrix_coo.cc:19-22
+        strcmp(tok[0], "%%MatrixMarket") != 0) {
+        *err = "Could not process Matrix Market banner.";   // matrix_coo.cc:19-22
+        return CGX_ERR_IO;
+    }
     for (int t = 1; t < 5; ++t)
         for (char *c = tok[t]; *c; ++c) *c = (char)tolower((unsigned char)*c);       // mmio.c lower-cases the tokens
-    if (strcmp(tok[1], "matrix") != 0 || strcmp(tok[2], "coordinate") != 0)
-        return fail(ctx, CGX_ERR_UNSUPPORTED, std::string("Sorry, this application does not support Market Market type: [") +
-                                                  tok[1] + " " + tok[2] + " " + tok[3] + " " + tok[4] + "]");   // matrix_coo.cc:25-29
+    if (strcmp(tok[1], "matrix") != 0 || strcmp(tok[2], "coordinate") != 0) {
+        *err = std::string("Sorry, this application does not support Market Market type: [") + tok[1] + " " + tok[2] + " " +
+               tok[3] + " " + tok[4] + "]";   // matrix_coo.cc:25-29
+        return CGX_ERR_UNSUPPORTED;
+    }
     // The reference parses every entry as "%d %d %lg" whatever the field (matrix_coo.cc:48); fields without
     // one real value per entry would be silently misread there and are rejected here.
-    if (strcmp(tok[3], "real") != 0 && strcmp(tok[3], "integer") != 0 && strcmp(tok[3], "double") != 0)
-        return fail(ctx, CGX_ERR_UNSUPPORTED, std::string("Matrix Market field not supported: ") + tok[3]);
-    const bool is_sym = strcmp(tok[4], "symmetric") == 0;                             // matrix_coo.cc:43
-    if (!is_sym && strcmp(tok[4], "general") != 0)
-        return fail(ctx, CGX_ERR_UNSUPPORTED, std::string("Matrix Market symmetry not supported: ") + tok[4]);
-
-    int m = 0, n = 0, nz = 0;
+    if (strcmp(tok[3], "real") != 0 && strcmp(tok[3], "integer") != 0 && strcmp(tok[3], "double") != 0) {
+        *err = std::string("Matrix Market field not supported: ") + tok[3];
+        return CGX_ERR_UNSUPPORTED;
+    }
+    out->sym = strcmp(tok[4], "symmetric") == 0;                                     // matrix_coo.cc:43
+    if (!out->sym && strcmp(tok[4], "general") != 0) {
+        *err = std::string("Matrix Market symmetry not supported: ") + tok[4];
+        return CGX_ERR_UNSUPPORTED;
+    }
     for (;;) {   // size line after the % comments, mmio.c:198-206
-        if (!fgets(line, sizeof line, f)) return fail(ctx, CGX_ERR_IO, "Matrix Market size line missing");
+        if (!fgets(line, sizeof line, f)) { *err = "Matrix Market size line missing"; return CGX_ERR_IO; }
         if (line[0] == '%') continue;
         long long lm = 0, ln = 0, lnz = 0;
         if (sscanf(line, "%lld %lld %lld", &lm, &ln, &lnz) == 3) {   // the reference reads three ints (mmio.c:204)
-            if (lm > 0x7fffffffLL || ln > 0x7fffffffLL || lnz > 0x7fffffffLL || lm < 0 || ln < 0 || lnz < 0)
-                return fail(ctx, CGX_ERR_UNSUPPORTED, "Matrix Market size line does not fit the reference's int sizes");
-            m = (int)lm;
-            n = (int)ln;
-            nz = (int)lnz;
+            if (lm > 0x7fffffffLL || ln > 0x7fffffffLL || lnz > 0x7fffffffLL || lm < 0 || ln < 0 || lnz < 0) {
+                *err = "Matrix Market size line does not fit the reference's int sizes";
+                return CGX_ERR_UNSUPPORTED;
+            }
+            out->m = (int)lm;
+            out->n = (int)ln;
+            out->nz = (int)lnz;
             break;
         }
     }
-    if (m <= 0 || n <= 0 || nz < 0 || m != n)
-        return fail(ctx, CGX_ERR_UNSUPPORTED, "CG needs a square matrix with positive size");
-    CGX_TRY(setup_problem(ctx, n));
-
-    // The entries are parsed from large reads of the file (strtol/strtod on a buffer: the "%d %d %lg" of
-    // matrix_coo.cc:48 without a libc call per field) and kept in file order; everything after that -- which row
-    // block an entry belongs to, the mirrored assignment of a symmetric file, and "a later entry for the same (i,j)
-    // overrides an earlier one" (the sequential loop of matrix.cc:12-21) -- is done on the device.
-    std::vector<int> hI, hJ;
-    std::vector<double> ha;
-    hI.reserve((size_t)nz);
-    hJ.reserve((size_t)nz);
-    ha.reserve((size_t)nz);
-    std::vector<int> offs;   // banded: distinct (column - row) of all assignments, at most CGX_MAX_DIAGONALS + 1 kept
-    auto note_offset = [&](int off) {
-        if (!ctx->banded || (int)offs.size() > CGX_MAX_DIAGONALS) return;
-        auto it = std::lower_bound(offs.begin(), offs.end(), off);
-        if (it == offs.end() || *it != off) offs.insert(it, off);
-    };
-    {
-        const size_t kChunk = (size_t)32 << 20;
-        std::vector<char> buf(kChunk + 4096);
-        size_t have = 0;            // bytes of an unfinished token carried over from the previous read
-        int field = 0, I = 0, J = 0;
-        bool eof = false;
-        while ((long)ha.size() < (long)nz && !(eof && have == 0)) {
-            if (have + kChunk + 1 > buf.size()) buf.resize(have + kChunk + 1);
-            const size_t got = eof ? 0 : fread(buf.data() + have, 1, kChunk, f);
-            if (got < kChunk) eof = true;
-            size_t len = have + got, cut = len;
-            if (!eof) {             // stop at the last white space so that no token is split
-                while (cut > 0 && !isspace((unsigned char)buf[cut - 1])) --cut;
-                if (cut == 0) return fail(ctx, CGX_ERR_IO, "Matrix Market entry " + std::to_string(ha.size()) + " unreadable");
-            }
-            const char saved = buf[cut];
-            buf[cut] = '\0';
-            char *p = buf.data();
-            while ((long)ha.size() < (long)nz) {
-                while (*p && isspace((unsigned char)*p)) ++p;
-                if (!*p) break;
-                char *e = p;
-                if (field < 2) {
-                    const long v = strtol(p, &e, 10);
-                    if (e == p) return fail(ctx, CGX_ERR_IO, "Matrix Market entry " + std::to_string(ha.size()) + " unreadable");
-                    if (v < 1 || v > 0x7fffffffL) return fail(ctx, CGX_ERR_IO, "Matrix Market index out of range");
-                    (field == 0 ? I : J) = (int)v;
-                    ++field;
-                } else {
-                    const double a = strtod(p, &e);
-                    if (e == p) return fail(ctx, CGX_ERR_IO, "Matrix Market entry " + std::to_string(ha.size()) + " unreadable");
-                    field = 0;
-                    I--; J--;                                                             // matrix_coo.cc:49-50
-                    if (I < 0 || I >= m || J < 0 || J >= n) return fail(ctx, CGX_ERR_IO, "Matrix Market index out of range");
-                    hI.push_back(I);
-                    hJ.push_back(J);
-                    ha.push_back(a);
-                    note_offset(J - I);                                                   // matrix.cc:17
-                    if (is_sym) note_offset(I - J);                                       // matrix.cc:18-20
-                }
-                p = e;
-            }
-            buf[cut] = saved;
-            have = len - cut;
-            memmove(buf.data(), buf.data() + cut, have);
-            if (eof && (long)ha.size() < (long)nz && have == 0) break;
-        }
-        if ((long)ha.size() < (long)nz)
-            return fail(ctx, CGX_ERR_IO, "Matrix Market entry " + std::to_string(ha.size()) + " unreadable");
+    if (out->m <= 0 || out->n <= 0 || out->nz < 0 || out->m != out->n) {
+        *err = "CG needs a square matrix with positive size";
+        return CGX_ERR_UNSUPPORTED;
     }
+    // the entries: the rest of the file, mapped if it is a regular file
+    Body body;
+    const long at = ftell(f);
+    struct stat st {};
+    if (at >= 0 && fstat(fileno(f), &st) == 0 && S_ISREG(st.st_mode) && st.st_size > at) {
+        void *mp = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(f), 0);
+        if (mp != MAP_FAILED) {
+            body.map = mp;
+            body.map_len = (size_t)st.st_size;
+            body.p = static_cast<const char *>(mp) + at;
+            body.len = (size_t)st.st_size - (size_t)at;
+        }
+    }
+    if (!body.map) {                                  // a pipe, or mmap refused: read what is left
+        char buf[1 << 16];
+        size_t got;
+        while ((got = fread(buf, 1, sizeof buf, f)) > 0) body.owned.insert(body.owned.end(), buf, buf + got);
+        body.p = body.owned.data();
+        body.len = body.owned.size();
+    }
+    out->I.assign((size_t)out->nz, 0);
+    out->J.assign((size_t)out->nz, 0);
+    out->a.assign((size_t)out->nz, 0.0);
+    *err = parse_entries(body.p, body.len, out->nz, out->m, out->n, out->I.data(), out->J.data(), out->a.data(), nthreads);
+    return err->empty() ? CGX_OK : CGX_ERR_IO;
+}
+
+int default_parse_threads()
+{
+    if (const char *e = getenv("CGX_MTX_THREADS")) return std::max(1, atoi(e));
+    const unsigned hc = std::thread::hardware_concurrency();
+    return (int)std::max(1u, std::min(hc ? hc : 1u, 16u));
+}
+
+}  // namespace cgxi
+
+extern "C" {
+
+// ---- MatrixCOO::read + Matrix::read, matrix_coo.cc:7-60 and matrix.cc:6-22 -------------------------
+cgx_status cgx_read_matrix(cgx_ctx *ctx, const char *path)
+{
+    if (!ctx || !path) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_read_matrix: bad argument");
+    // The entries are parsed on the host threads from the mapped file (parse_matrix_market) and kept in file order;
+    // everything after that -- which row block an entry belongs to, the mirrored assignment of a symmetric file, and "a
+    // later entry for the same (i,j) overrides an earlier one" (the sequential loop of matrix.cc:12-21) -- is done on the
+    // device.
+    MtxEntries mtx;
+    {
+        std::string err;
+        const cgx_status st = parse_matrix_market(path, &mtx, &err, default_parse_threads());
+        if (st != CGX_OK) return fail(ctx, st, err);
+    }
+    const int n = mtx.n;
+    const bool is_sym = mtx.sym;
+    CGX_TRY(setup_problem(ctx, n));
+    std::vector<int> &hI = mtx.I, &hJ = mtx.J;
+    std::vector<double> &ha = mtx.a;
+    std::vector<int> offs;   // banded: distinct (column - row) of all assignments, at most CGX_MAX_DIAGONALS + 1 kept
+    if (ctx->banded)
+        for (size_t z = 0; z < ha.size() && (int)offs.size() <= CGX_MAX_DIAGONALS; ++z)
+            for (int mir = 0; mir <= (is_sym ? 1 : 0); ++mir) {                       // matrix.cc:17, 18-20
+                const int off = mir ? hI[z] - hJ[z] : hJ[z] - hI[z];
+                auto it = std::lower_bound(offs.begin(), offs.end(), off);
+                if (it == offs.end() || *it != off) offs.insert(it, off);
+            }
     if (ctx->banded && (int)offs.size() > CGX_MAX_DIAGONALS)
         return fail(ctx, CGX_ERR_UNSUPPORTED, "matrix has more than " + std::to_string(CGX_MAX_DIAGONALS) +
                                                   " non-zero diagonals: not a banded matrix (use CGX_MATRIX_DENSE)");

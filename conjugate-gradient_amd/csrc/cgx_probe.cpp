@@ -137,6 +137,31 @@ cgx_status cgx_probe_set_fault_after(cgx_ctx *ctx, int calls)
     return CGX_OK;
 }
 
+// Host only (no context, no device): the Matrix-Market parser by itself.
+cgx_status cgx_probe_parse_matrix_market(const char *path, int threads, int *m, int *n, int *nz, int *symmetric, int *I, int *J,
+                                         double *a, long cap, char *err, int err_cap)
+{
+    if (!path) return CGX_ERR_BAD_ARG;
+    MtxEntries e;
+    std::string msg;
+    const cgx_status st = parse_matrix_market(path, &e, &msg, threads == 0 ? default_parse_threads() : threads);
+    if (err && err_cap > 0) {
+        strncpy(err, msg.c_str(), (size_t)err_cap - 1);
+        err[err_cap - 1] = '\0';
+    }
+    if (st != CGX_OK) return st;
+    if (m) *m = e.m;
+    if (n) *n = e.n;
+    if (nz) *nz = e.nz;
+    if (symmetric) *symmetric = e.sym ? 1 : 0;
+    for (long z = 0; z < cap && z < (long)e.a.size(); ++z) {
+        if (I) I[z] = e.I[(size_t)z];
+        if (J) J[z] = e.J[(size_t)z];
+        if (a) a[z] = e.a[(size_t)z];
+    }
+    return CGX_OK;
+}
+
 cgx_status cgx_probe_set_resident_limit(cgx_ctx *ctx, int workgroups)
 {
     if (!ctx) return CGX_ERR_BAD_ARG;

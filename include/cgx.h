@@ -220,6 +220,12 @@ cgx_status  cgx_probe_vector_ops(cgx_ctx *ctx, int n, double alpha, double beta,
  * failure instead (-1 = off).  TEST-ONLY: tools/leak_check.py and tests/ use it to walk every early return of a probe,
  * the self-test and the solve; nothing else (no environment variable) arms it. */
 cgx_status  cgx_probe_set_fault_after(cgx_ctx *ctx, int calls);
+/* The Matrix-Market parser of cgx_read_matrix by itself, HOST ONLY (no context, no device): header checks as
+ * matrix_coo.cc:19-40, then the nz entries "%d %d %lg" (matrix_coo.cc:44-55) parsed from the mapped file on `threads` host
+ * threads (0 = the library's default; negative = exactly that many, however small the file) into 0-based I, J and a in
+ * file order; at most `cap` entries are written (call with cap = 0 for the sizes).  err (may be NULL) receives the message. */
+cgx_status  cgx_probe_parse_matrix_market(const char *path, int threads, int *m, int *n, int *nz, int *symmetric, int *I, int *J,
+                                          double *a, long cap, char *err, int err_cap);
 /* Test hook for the co-residency guard of CGX_COMM_P2P's fused update kernel (its workgroups wait for each other inside the
  * kernel, so its grid must not exceed what the device keeps resident: occupancy x CUs, queried from the runtime when a
  * problem is set): workgroups > 0 replaces the queried bound for the problems set afterwards, 0 restores it. */
