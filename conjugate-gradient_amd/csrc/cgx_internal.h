@@ -205,7 +205,7 @@ struct MtxEntries {
     std::vector<int> I, J;
     std::vector<double> a;
 };
-cgx_status parse_matrix_market(const char *path, MtxEntries *out, std::string *err, int nthreads);
+cgx_status parse_matrix_market(const char *path, MtxEntries *out, std::string *err, int nthreads, bool header_only = false);
 int default_parse_threads();   // CGX_MTX_THREADS, else the host's hardware threads, at most 16
 
 // cgx_solve.cpp

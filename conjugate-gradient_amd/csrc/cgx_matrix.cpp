@@ -257,7 +257,7 @@ std::string parse_entries(const char *data, size_t len, long nz, int m, int n, i
 }  // namespace
 
 // Header (mmio.c:96-179,189-217 as matrix_coo.cc:19-40 uses them) + entries.  err: CGX_ERR_IO / CGX_ERR_UNSUPPORTED text.
-cgx_status parse_matrix_market(const char *path, MtxEntries *out, std::string *err, int nthreads)
+cgx_status parse_matrix_market(const char *path, MtxEntries *out, std::string *err, int nthreads, bool header_only)
 {
     FILE *f = fopen(path, "r");
     if (!f) { *err = std::string("Could not open matrix: ") + path; return CGX_ERR_IO; }   // matrix_coo.cc:14-17
@@ -311,6 +311,7 @@ cgx_status parse_matrix_market(const char *path, MtxEntries *out, std::string *e
         *err = "CG needs a square matrix with positive size";
         return CGX_ERR_UNSUPPORTED;
     }
+    if (header_only) return CGX_OK;
     // the entries: the rest of the file, mapped if it is a regular file
     Body body;
     const long at = ftell(f);

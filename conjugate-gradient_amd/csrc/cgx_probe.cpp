@@ -144,7 +144,7 @@ cgx_status cgx_probe_parse_matrix_market(const char *path, int threads, int *m, 
     if (!path) return CGX_ERR_BAD_ARG;
     MtxEntries e;
     std::string msg;
-    const cgx_status st = parse_matrix_market(path, &e, &msg, threads == 0 ? default_parse_threads() : threads);
+    const cgx_status st = parse_matrix_market(path, &e, &msg, threads == 0 ? default_parse_threads() : threads, cap <= 0);   // cap 0: the sizes only
     if (err && err_cap > 0) {
         strncpy(err, msg.c_str(), (size_t)err_cap - 1);
         err[err_cap - 1] = '\0';

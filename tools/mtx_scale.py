@@ -13,6 +13,10 @@ t0 = time.time()
 open(path, "w").write(make_lap2d_5pt.generate(g))
 print("file: %.1f MB, written in %.1f s" % (os.path.getsize(path) / 1e6, time.time() - t0), flush=True)
 n = g * g
+for threads in (1, 4, 0):          # the parser alone (host only): one thread, four, the library's default
+    t0 = time.time(); m_, n_, sym_, I, J, a = pkg.cgx.parse_matrix_market(path, threads); dt = time.time() - t0
+    print("parse only, threads=%s: %.3f s (%.0f MB/s, %.1f M entries/s)" % (threads or "default", dt, os.path.getsize(path) / 1e6 / dt, len(a) / 1e6 / dt), flush=True)
+    del I, J, a
 with pkg.CGSolver(matrix_format=pkg.MATRIX_BANDED) as s:
     t0 = time.time(); s.read_matrix(path); t1 = time.time()
     print("cgx_read_matrix: %.2f s for n=%d; diagonals %s" % (t1 - t0, n, s.matrix_format(0)[1]), flush=True)
