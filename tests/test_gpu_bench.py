@@ -242,3 +242,21 @@ def test_bench_update_kernel_timing_on_request(gpu_pkg):
     assert d["update_kernel"]["kernel"].startswith("k_update_xr (K3)") and u["launches_timed"] == 19
     assert 0 < u["min_ms"] <= u["median_ms"] <= u["max_ms"]
     assert d["roofline"]["median_launch_ms"] + u["median_ms"] <= d["ms_per_step"] and d["roofline"]["consistency"] == "ok"
+
+
+def test_bench_self_launch_weak_mode_two_ranks(gpu_pkg, oracle):
+    """configs[4] at P = 2 through the self-launch path: `python3 bench.py --gpus 2 --mode weak` picks N = floor(16384 sqrt 2) =
+    23170 (code/MPI/cg.run:22-44), 11585 rows per rank, scaling "weak"; both ranks share the one GPU (gloo control plane).
+    Residual after 25 iterations against the oracle's on-the-fly twin with the same partition."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--mode", "weak", "--steps", "20", "--warmup", "5", "--no-solve-window",
+                        "--cpu-baseline-iters", "3"], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, CGX_BENCH_BACKEND="gloo"))
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    d = one_line(r.stdout)
+    c = d["config"]
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and c["n"] == 23170 and "configs[4]" in c["workload"]
+    assert [q["rows"] for q in d["k1_per_rank"]] == [11585, 11585] and c["ranks_seen"] == 2
+    assert all(pl["split"] == 8 and pl["light"] == 1 for pl in c["k1_plan"])
+    assert d["iterations_done"] == 25 and "N=23170" in d["cpu_baseline"]["sample"]
+    _, ro = oracle.solve_lap2d_banded(23170, 25, 0.0, 2)
+    assert abs(d["residual_after_run"] - ro["residual_prev"]) <= 1e-6 * ro["residual_prev"]
