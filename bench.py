@@ -26,13 +26,18 @@ Rank 0 ALWAYS prints a line: if no transport produces a result, if an exception 
 has "value": null and an "error" object.
 """
 import argparse
+import csv
+import glob
 import json
 import math
 import os
+import re
+import shutil
 import signal
 import socket
 import subprocess
 import sys
+import tempfile
 import threading
 import time
 import traceback
@@ -68,6 +73,9 @@ def parse_args():
                          "default: on for several GPUs (its duration then holds the wait for the peers = the cost of the exchange), "
                          "off on one (a timed dispatch costs ~5 us of stream time)")
     ap.add_argument("--no-solve-window", action="store_true", help="skip the extra untimed solve() through the reference's window")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="do not collect K1's HBM traffic with two rocprofv3 --pmc child passes of this program (one GPU only, "
+                         "after the timed region; ~20 s); roofline.traffic then comes from the committed file or is null")
     ap.add_argument("--wireup-timeout", type=float, default=float(os.environ.get("CGX_BENCH_WIREUP_TIMEOUT", "90")),
                     help="seconds one transport's wire-up stage may take before that transport is dropped")
     ap.add_argument("--watchdog", type=float, default=float(os.environ.get("CGX_BENCH_WATCHDOG", "480")),
@@ -90,6 +98,42 @@ def pmc_traffic(n, nranks, plan):
                 {k: int(r.get("plan", {}).get(k, -1)) for k in want} == want:
             return r.get("hbm_bytes_per_launch")
     return None
+
+
+K1_FUSED = re.compile(r"k_gemv_colsplit<\d+, \d+, \d+, 1(?:, (?:true|false))*>|k_gemv_ldsp<\d+, \d+, \d+, 1>")
+
+
+def live_pmc_traffic(args, n):
+    """K1's HBM bytes per launch ON THIS BOX, NOW: two short child runs of this same program under rocprofv3 --pmc -- FETCH_SIZE,
+    then WRITE_SIZE, separate passes with --kernel-trace only, corrected as /opt/skills/guides/MI355X_MICROARCH.md prescribes
+    (on gfx950 FETCH_SIZE counts the 128-B requests of a wide coalesced read at 64 B: read bytes = FETCH_SIZE x 1024 x 2;
+    WRITE_SIZE x 1024 is exact).  One GPU only.  Returns (bytes per launch or None, note)."""
+    exe = shutil.which("rocprofv3")
+    if exe is None:
+        return None, "rocprofv3 not on PATH"
+    if any(k.startswith(("ROCP_", "ROCPROF")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process already runs under a profiler"
+    means, launches = {}, 0
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="cgx_pmc_", dir="/tmp")
+        try:
+            cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
+                   os.path.abspath(__file__), "--steps", "20", "--warmup", "5", "--matrix-size", str(n), "--variant", str(args.variant),
+                   "--lda-pad", str(args.lda_pad), "--no-cpu-baseline", "--no-solve-window", "--no-live-pmc", "--no-profile-gemv"]
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s pass failed (rc %d): %s" % (counter, r.returncode, r.stderr[-300:])
+            vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
+                    if row["Counter_Name"] == counter and K1_FUSED.search(row["Kernel_Name"])]
+            if not vals:
+                return None, "no K1 dispatch in the %s pass" % counter
+            means[counter], launches = sum(vals) / len(vals), len(vals)
+        except Exception as e:                     # noqa: BLE001 -- a measurement aid must never cost the line
+            return None, "%s pass: %s" % (counter, str(e)[:200])
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return means["FETCH_SIZE"] * 1024 * 2 + means["WRITE_SIZE"] * 1024, "%d K1 launches per pass" % launches
 
 
 def broadcast_bytes(dist, payload, nbytes, device):
@@ -650,6 +694,20 @@ class Bench:
         # for a reader of a GPU-utilisation sampler beside this line: how much device work the process did in all (the
         # rest of a 1-GPU run's wall time is the CPU baseline, which keeps the GPU idle)
         line["gpu_work"] = {"seconds_in_timed_loops": self.gpu_work_s, "cg_iterations_on_device": self.gpu_iterations}
+        if world == 1 and not args.no_live_pmc and lim is not None:
+            # the traffic of THIS box, by counters, instead of the committed constant: two rocprofv3 --pmc child passes of the
+            # same workload (after the timed region; the parent keeps its own matrix, the child builds another)
+            self.state["stage"] = "live PMC passes"
+            live, note = live_pmc_traffic(args, n)
+            roof["traffic_committed"] = roof["traffic"]
+            if live is not None:
+                roof["traffic"] = live
+                roof["traffic_over_algorithmic"] = live / lim["bytes_per_launch"]
+                roof["traffic_source"] = ("LIVE: two rocprofv3 --pmc child passes of this program on this box, FETCH_SIZE then WRITE_SIZE, "
+                                          "--kernel-trace only (%s); read bytes = FETCH_SIZE x 1024 x 2 (the guide's gfx950 correction), "
+                                          "WRITE_SIZE x 1024 exact; traffic_committed = the row of %s for the same K1 plan" % (note, TRAFFIC_FILE))
+            else:
+                roof["traffic_live_note"] = note
         if not args.no_cpu_baseline:
             # rank 0 only, after the timed region and outside every bracket; the other ranks wait at the teardown barrier
             self.state["stage"] = "cpu baseline"

@@ -44,6 +44,10 @@ def test_bench_line_contract(gpu_pkg):
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
     assert "error" not in d
+    # roofline.traffic: by default counters of THIS box (two rocprofv3 --pmc child passes of the same workload), per launch
+    assert rf["traffic_source"].startswith("LIVE"), rf.get("traffic_live_note")
+    assert 0.9 < rf["traffic_over_algorithmic"] < 1.2 and abs(rf["traffic"] - rf["traffic_over_algorithmic"] * rf["bytes_per_launch"]) < 1.0
+    assert rf["traffic_committed"] is None          # no committed row for N = 4096
 
 
 def test_bench_short_window_statistics(gpu_pkg, oracle):
@@ -51,7 +55,7 @@ def test_bench_short_window_statistics(gpu_pkg, oracle):
     fraction is computed from, a K1 launch never outlasts the step it is part of, and the run is the reference's
     recurrence (residual after 25 iterations against the oracle)."""
     n = 8192
-    r = subprocess.run([sys.executable, BENCH, "--steps", "20", "--warmup", "5", "--matrix-size", str(n), "--no-cpu-baseline"],
+    r = subprocess.run([sys.executable, BENCH, "--steps", "20", "--warmup", "5", "--matrix-size", str(n), "--no-cpu-baseline", "--no-live-pmc"],
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = one_line(r.stdout)
@@ -128,7 +132,7 @@ def test_bench_prints_a_failure_line_when_no_transport_works(gpu_pkg):
 
 def test_bench_watchdog_prints_a_failure_line(gpu_pkg):
     """A run that cannot finish inside the watchdog still ends with one parseable line."""
-    r = subprocess.run([sys.executable, BENCH, "--steps", "500", "--warmup", "100", "--watchdog", "0.2", "--no-cpu-baseline"],
+    r = subprocess.run([sys.executable, BENCH, "--steps", "500", "--warmup", "100", "--watchdog", "0.2", "--no-cpu-baseline", "--no-live-pmc"],
                        capture_output=True, text=True, timeout=300)
     d = one_line(r.stdout)
     assert d["value"] is None and d["error"]["kind"] == "watchdog"
@@ -235,7 +239,7 @@ def test_bench_self_launch_refuses_more_ranks_than_gpus(gpu_pkg):
 def test_bench_update_kernel_timing_on_request(gpu_pkg):
     """--profile-update on one GPU: K3 of every iteration whose K1 is timed gets its own event pair; K1 + K3 stay below the step."""
     r = subprocess.run([sys.executable, BENCH, "--steps", "20", "--warmup", "5", "--matrix-size", "8192", "--no-cpu-baseline",
-                        "--no-solve-window", "--profile-update"], capture_output=True, text=True, timeout=600)
+                        "--no-solve-window", "--profile-update", "--no-live-pmc"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     d = one_line(r.stdout)
     u = d["update_kernel"]["per_rank"][0]

@@ -16,7 +16,7 @@ mkdir -p $R/gpurun_out/pmc
 for c in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do
   tag=$(echo $c | cut -d' ' -f1)
   rm -rf /tmp/pmcb_$tag
-  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcb_$tag -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $R/gpurun_out/pmc/bench20_$tag.json 2> /tmp/pmcb_$tag.log
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcb_$tag -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-live-pmc > $R/gpurun_out/pmc/bench20_$tag.json 2> /tmp/pmcb_$tag.log
   cp "$(find /tmp/pmcb_$tag -name '*counter_collection.csv' | head -1)" /tmp/pmc_raw_bench20_${tag}.csv
 done
 for PN in 2:32768 4:32768 8:32768 1:16384; do

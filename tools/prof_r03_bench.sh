@@ -9,11 +9,11 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $OUT/bench_default_n32768.json 2> $OUT/bench_default.err
 echo "default line done"
-rm -rf /tmp/prof_b20; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b20 -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/bench20_line_under_rocprofv3.json 2> $OUT/bench20.err
+rm -rf /tmp/prof_b20; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_b20 -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-live-pmc > $OUT/bench20_line_under_rocprofv3.json 2> $OUT/bench20.err
 cp "$(find /tmp/prof_b20 -name '*kernel_stats.csv' | head -1)" $OUT/bench20_kernel_stats.csv
 python3 $R/bench.py --steps 20 --warmup 5 > $OUT/bench20_line.json 2>> $OUT/bench20.err
 echo "driver line done"
-rm -rf /tmp/prof_weak; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_weak -- python3 $R/bench.py --mode weak --steps 200 --no-cpu-baseline > $OUT/weak_base_n16384_line_under_rocprofv3.json 2> $OUT/weak.err
+rm -rf /tmp/prof_weak; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_weak -- python3 $R/bench.py --mode weak --steps 200 --no-cpu-baseline --no-live-pmc > $OUT/weak_base_n16384_line_under_rocprofv3.json 2> $OUT/weak.err
 cp "$(find /tmp/prof_weak -name '*kernel_stats.csv' | head -1)" $OUT/weak_base_n16384_kernel_stats.csv
 python3 $R/bench.py --mode weak --steps 200 > $OUT/weak_base_n16384_line.json 2>> $OUT/weak.err
 echo "weak base done"
