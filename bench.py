@@ -18,6 +18,9 @@ Extra objects in the line:
   roofline     -- K1 (the GEMV) against the 8 TB/s HBM peak: algorithmic bytes 8*(rows*N + N + rows) per launch
                   divided by the MEDIAN launch duration of the timed region, measured with HIP events bound to the K1
                   dispatches on the library's own stream (the first launch after the sync is never a sample).
+                  roofline.traffic = HBM bytes per K1 launch by PMC counters: on one GPU counted on THIS box by two
+                  rocprofv3 --pmc child passes of the same workload after the timed region, else the committed row of
+                  profiles/k1_hbm_traffic.json for the same K1 plan, else null.
   cpu_baseline -- the CPU oracle (oracle/cg_oracle.c, a port of the reference's serial path) run for a few
                   iterations of the same workload on one host core (rank 0, after the timed region, at any N).
   solve_window -- the same K iterations through the reference's own timing window (all of solve(), cg_main.cc:53-55).
