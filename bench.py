@@ -123,7 +123,7 @@ def live_pmc_traffic(args, n):
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.abspath(__file__), "--steps", "20", "--warmup", "5", "--matrix-size", str(n), "--variant", str(args.variant),
                    "--lda-pad", str(args.lda_pad), "--no-cpu-baseline", "--no-solve-window", "--no-live-pmc", "--no-profile-gemv"]
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=240)
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=100)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, "rocprofv3 --pmc %s pass failed (rc %d): %s" % (counter, r.returncode, r.stderr[-300:])
@@ -697,6 +697,9 @@ class Bench:
         # for a reader of a GPU-utilisation sampler beside this line: how much device work the process did in all (the
         # rest of a 1-GPU run's wall time is the CPU baseline, which keeps the GPU idle)
         line["gpu_work"] = {"seconds_in_timed_loops": self.gpu_work_s, "cg_iterations_on_device": self.gpu_iterations}
+        # From here on only extras are added (live counters, CPU baseline): the measurement is complete.  A snapshot goes to
+        # the watchdog, so that an extra that hangs costs the extras, never the line.
+        self.state["line_snapshot"] = json.dumps(line)
         if world == 1 and not args.no_live_pmc and lim is not None:
             # the traffic of THIS box, by counters, instead of the committed constant: two rocprofv3 --pmc child passes of the
             # same workload (after the timed region; the parent keeps its own matrix, the child builds another)
@@ -714,6 +717,8 @@ class Bench:
         if not args.no_cpu_baseline:
             # rank 0 only, after the timed region and outside every bracket; the other ranks wait at the teardown barrier
             self.state["stage"] = "cpu baseline"
+            if os.environ.get("CGX_BENCH_TEST_HANG") == "extra:cpu baseline":   # test hook: an extra that never comes back
+                time.sleep(3600)
             line["cpu_baseline"] = cpu_baseline(n, args.cpu_baseline_iters)
         return line
 
@@ -822,6 +827,13 @@ def main():
     def on_watchdog():
         printed = state["printed"]
         stop_launched()
+        if state.get("line_snapshot") and not printed:
+            # the timed result exists; what hung is an extra (live PMC passes, CPU baseline): print the measurement without it
+            snap = json.loads(state["line_snapshot"])
+            snap["watchdog_note"] = "stage '%s' did not finish within the %.0f s watchdog; the line is complete up to it" % (state["stage"], args.watchdog)
+            emit(snap)
+            print("bench.py rank %d: watchdog expired in stage '%s' (line printed without it)" % (rank, state["stage"]), file=sys.stderr, flush=True)
+            os._exit(0)
         emit(failure_line("watchdog", "no result after %.0f s" % args.watchdog))
         print("bench.py rank %d: watchdog expired in stage '%s'" % (rank, state["stage"]), file=sys.stderr, flush=True)
         os._exit(0 if printed else 3)
