@@ -123,7 +123,10 @@ def live_pmc_traffic(args, n):
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.abspath(__file__), "--steps", "20", "--warmup", "5", "--matrix-size", str(n), "--variant", str(args.variant),
                    "--lda-pad", str(args.lda_pad), "--no-cpu-baseline", "--no-solve-window", "--no-live-pmc", "--no-profile-gemv"]
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=100)
+            env = {k: v for k, v in os.environ.items()           # the child is a plain one-GPU run, never a rank of somebody's job
+                   if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR",
+                                "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(env, TMPDIR="/tmp"), capture_output=True, text=True, timeout=100)
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
             if r.returncode != 0 or not files:
                 return None, "rocprofv3 --pmc %s pass failed (rc %d): %s" % (counter, r.returncode, r.stderr[-300:])
@@ -700,7 +703,7 @@ class Bench:
         # From here on only extras are added (live counters, CPU baseline): the measurement is complete.  A snapshot goes to
         # the watchdog, so that an extra that hangs costs the extras, never the line.
         self.state["line_snapshot"] = json.dumps(line)
-        if world == 1 and not args.no_live_pmc and lim is not None:
+        if world == 1 and transport == "self" and not args.no_live_pmc and lim is not None:
             # the traffic of THIS box, by counters, instead of the committed constant: two rocprofv3 --pmc child passes of the
             # same workload (after the timed region; the parent keeps its own matrix, the child builds another)
             self.state["stage"] = "live PMC passes"
