@@ -30,7 +30,7 @@ EXPORTS = [
     "cgx_get_update_samples",
     "cgx_probe_gemv", "cgx_probe_time_gemv", "cgx_probe_vector_ops", "cgx_probe_get_matrix_rows",
     "cgx_probe_get_source_term", "cgx_probe_set_fault_after", "cgx_probe_set_resident_limit",
-    "cgx_probe_parse_matrix_market",
+    "cgx_probe_parse_matrix_market", "cgx_probe_p2p_mailbox_to_host",
 ]
 
 
@@ -131,6 +131,7 @@ def lib():
         L.cgx_probe_get_source_term.argtypes = [vp, C.c_int, dp]
         L.cgx_probe_set_fault_after.argtypes = [vp, C.c_int]
         L.cgx_probe_set_resident_limit.argtypes = [vp, C.c_int]
+        L.cgx_probe_p2p_mailbox_to_host.argtypes = [vp]
         L.cgx_probe_parse_matrix_market.argtypes = [C.c_char_p, C.c_int, ip, ip, ip, ip, ip, ip, dp, C.c_long, C.c_char_p, C.c_int]
         for name in EXPORTS:
             fn = getattr(L, name)
@@ -386,6 +387,10 @@ class CGSolver:
     def _set_fault_after(self, calls):
         """Error-path tests: the HIP call after `calls` more of this context fails (-1 = off)."""
         lib().cgx_probe_set_fault_after(self._h, int(calls))
+
+    def _mailbox_to_host(self):
+        """Test hook: the mailbox of a one-rank P2P context moves to pinned coherent host memory (exchange over PCIe)."""
+        self._check(lib().cgx_probe_p2p_mailbox_to_host(self._h))
 
     def _set_resident_limit(self, workgroups):
         """Test hook: bound of co-resident workgroups the fused P2P update may assume (0 = ask the runtime)."""

@@ -596,7 +596,7 @@ cgx_status cgx_destroy(cgx_ctx *ctx)
     if (ctx->cfg.comm_mode == CGX_COMM_P2P) {
         for (int q = 0; q < ctx->nranks; ++q)
             if (q != ctx->cfg.rank && ctx->mv.base[q]) (void)hipIpcCloseMemHandle(ctx->mv.base[q]);
-        if (ctx->mailbox) (void)hipFree(ctx->mailbox);
+        if (ctx->mailbox) (void)(ctx->mailbox_on_host ? hipHostFree(ctx->mailbox) : hipFree(ctx->mailbox));
         if (ctx->d_p2p_err) (void)hipFree(ctx->d_p2p_err);
     }
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);

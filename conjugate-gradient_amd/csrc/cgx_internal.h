@@ -66,6 +66,7 @@ struct cgx_ctx {
     // direct peer exchange (CGX_COMM_P2P)
     unsigned char *mailbox = nullptr;        // own fine-grained mailbox
     size_t mailbox_bytes = 0;
+    bool mailbox_on_host = false;            // test only (cgx_probe_p2p_mailbox_to_host): the mailbox lives in pinned host memory
     bool p2p_ready = false;                  // peers' mailboxes are mapped
     cgx::MailboxView mv{};
     unsigned long long p2p_epoch[cgx::kP2pChannels] = {0, 0, 0};

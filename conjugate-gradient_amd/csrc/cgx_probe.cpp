@@ -162,6 +162,26 @@ cgx_status cgx_probe_parse_matrix_market(const char *path, int threads, int *m, 
     return CGX_OK;
 }
 
+// TEST ONLY: move the mailbox of a ONE-rank P2P context into pinned, coherent HOST memory.  Every store of the exchange then
+// leaves the device over PCIe and every poll and load comes back over it: the system-scope path for real (not a neighbour
+// GPU over xGMI, but memory that is neither this GPU's HBM nor behind its L2), at several times the latency.  What a
+// one-GPU box can offer towards "nothing rests on how local memory happens to behave".
+cgx_status cgx_probe_p2p_mailbox_to_host(cgx_ctx *ctx)
+{
+    if (!ctx || ctx->cfg.comm_mode != CGX_COMM_P2P || ctx->nranks != 1 || !ctx->shards.empty())
+        return fail(ctx, CGX_ERR_BAD_ARG, "cgx_probe_p2p_mailbox_to_host: a one-rank P2P context without a problem");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    unsigned char *host = nullptr;
+    HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&host), ctx->mailbox_bytes, hipHostMallocCoherent | hipHostMallocMapped));
+    memset(host, 0, ctx->mailbox_bytes);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    (void)(ctx->mailbox_on_host ? hipHostFree(ctx->mailbox) : hipFree(ctx->mailbox));
+    ctx->mailbox = host;
+    ctx->mailbox_on_host = true;
+    ctx->mv.base[ctx->cfg.rank] = host;
+    return CGX_OK;
+}
+
 cgx_status cgx_probe_set_resident_limit(cgx_ctx *ctx, int workgroups)
 {
     if (!ctx) return CGX_ERR_BAD_ARG;

@@ -226,6 +226,9 @@ cgx_status  cgx_probe_set_fault_after(cgx_ctx *ctx, int calls);
  * file order; at most `cap` entries are written (call with cap = 0 for the sizes).  err (may be NULL) receives the message. */
 cgx_status  cgx_probe_parse_matrix_market(const char *path, int threads, int *m, int *n, int *nz, int *symmetric, int *I, int *J,
                                           double *a, long cap, char *err, int err_cap);
+/* TEST ONLY: moves the mailbox of a ONE-rank CGX_COMM_P2P context (no problem set yet) into pinned, coherent host memory, so
+ * that every store, poll and load of the exchange crosses PCIe: the system-scope path outside this GPU's HBM and L2. */
+cgx_status  cgx_probe_p2p_mailbox_to_host(cgx_ctx *ctx);
 /* Test hook for the co-residency guard of CGX_COMM_P2P's fused update kernel (its workgroups wait for each other inside the
  * kernel, so its grid must not exceed what the device keeps resident: occupancy x CUs, queried from the runtime when a
  * problem is set): workgroups > 0 replaces the queried bound for the problems set afterwards, 0 restores it. */

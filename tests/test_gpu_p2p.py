@@ -136,3 +136,36 @@ def test_fused_update_refuses_a_grid_the_device_cannot_keep_resident(oracle):
         r = s.solve(x)
     xo, ro = oracle.solve_lap2d(n + 2, 60, 1e-10, 1)
     assert r["iterations"] == 60 and np.linalg.norm(x - xo) <= 1e-12 * np.linalg.norm(xo)
+
+
+@pytest.mark.parametrize("tagged", [False, True])
+def test_exchange_through_host_memory_gives_the_same_bits(oracle, tagged):
+    """The mailbox in pinned, coherent HOST memory (test hook): every store of the fused exchange leaves the GPU over PCIe,
+    every poll and load comes back over it -- memory that is neither this GPU's HBM nor behind its L2, at several times the
+    latency.  The self-test must pass and the solve must give bit-identical results to the same solve over the device mailbox:
+    the protocol does not rest on how local memory happens to behave.  Both forms of the exchange."""
+    import numpy as np
+    import torch  # noqa: F401 -- before libcgx
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    n, iters = 6000, 80                         # 12 chunks; 24 workgroups
+    out = []
+    for on_host in (False, True):
+        with pkg.CGSolver(comm_mode=pkg.COMM_P2P, nranks=1, p2p_tagged=tagged, p2p_timeout_ms=20000) as s:
+            if on_host:
+                s._mailbox_to_host()
+            assert s.p2p_selftest(8)
+            s.generate_lap2d_matrix(n)
+            s.set_max_iter(iters)
+            s.tolerance(0.0)
+            s.init_source_term(1.0 / n)
+            x = np.zeros(n)
+            r = s.solve(x)
+            out.append((x, r))
+    (xd, rd), (xh, rh) = out
+    assert rd["iterations"] == rh["iterations"] == iters
+    assert np.array_equal(xd, xh) and rd["residual_prev"] == rh["residual_prev"] and rd["x_norm"] == rh["x_norm"]
+    xo, ro = oracle.solve_lap2d(n, iters, 0.0, 1)
+    assert np.linalg.norm(xh - xo) <= 1e-12 * np.linalg.norm(xo)
+    print("loop seconds: device mailbox %.4f, host mailbox %.4f" % (rd["seconds_loop"], rh["seconds_loop"]))
