@@ -179,8 +179,13 @@ std::string parse_entries(const char *data, size_t len, long nz, int m, int n, i
     std::vector<long> count((size_t)nthreads, 0);
     auto in_threads = [&](const std::function<void(int)> &body) {
         std::vector<std::thread> th;
-        for (int t = 1; t < nthreads; ++t) th.emplace_back(body, t);
+        int started = 1;                                                          // range 0 runs on the calling thread
+        try {
+            for (; started < nthreads; ++started) th.emplace_back(body, started);
+        } catch (...) {                                                           // no more threads to be had: the rest runs here
+        }
         body(0);
+        for (int t = started; t < nthreads; ++t) body(t);
         for (auto &x : th) x.join();
     };
     in_threads([&](int t) {
