@@ -406,7 +406,9 @@ int main(int argc, char **argv)
             }
         }
     } catch (const std::exception &e) {
-        std::cerr << "cgsolver (rank " << rank << "): " << e.what() << std::endl;
+        // one write per message: the ranks share stderr and tend to fail together
+        const std::string msg = "cgsolver (rank " + std::to_string(rank) + "): " + e.what() + "\n";
+        if (write(2, msg.data(), msg.size()) < 0) {}
         rc = 1;
     }
 
