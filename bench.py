@@ -623,9 +623,9 @@ class Bench:
                               "%s (FETCH_SIZE x2 + WRITE_SIZE per the guide's gfx950 correction); NOT a counter of this "
                               "run; null when no committed row matches the plan that ran" % TRAFFIC_FILE,
             "kernel": "k_gemv (K1, A.p of this rank's row block)",
-            "timing": "HIP events bound to the K1 dispatch (kernel begin/end) on the library's stream, every %s launch "
+            "timing": "HIP events bound to the K1 dispatch (kernel begin/end) on the library's stream, every %slaunch "
                       "of the timed region, median; the first launch after the sync is not sampled"
-                      % ("" if self.profile_every == 1 else "%d-th" % self.profile_every),
+                      % ("" if self.profile_every == 1 else "%d-th " % self.profile_every),
         }
         if lim is not None:
             ok = lim["median_ms"] <= ms_per_step          # a kernel that runs once per step cannot outlast the step
