@@ -94,9 +94,11 @@ typedef struct cgx_config {
     int  p2p_no_acquire_fence; /* diagnostics only: 1 = leave out the system-scope acquire fence behind the flag wait of the
                                  fused update kernel (for measuring its cost); default 0 = fence on */
     int  p2p_tagged;          /* CGX_COMM_P2P with the exchange folded into the update kernel: 1 = hand the bytes over as tagged
-                                 8-byte words (each carries half a double and the epoch: no flags, no fences, nothing but relaxed
-                                 8-byte system-scope atomics); 0 = payload stores + release, flag words, polls
-                                 + acquire.  Both forms are checked by cgx_p2p_selftest with their own device code.  (Was reserved[0].) */
+                                 8-byte words (each carries half a double and the epoch and validates itself: no flags, no
+                                 fences; the two words of a double leave as one 16-byte write-through store, readers poll with
+                                 relaxed 8-byte system-scope atomic loads); 0 = payload stores + release,
+                                 flag words, polls + acquire.  Both forms are checked by cgx_p2p_selftest with their own device
+                                 code.  (Was reserved[0].) */
 } cgx_config;
 
 typedef struct cgx_result {
