@@ -389,6 +389,16 @@ int oracle_read_mtx_dense(const char *path, int *m_out, int *n_out, int *nz_out,
 
 void oracle_set_threads(int nthreads) { g_threads = nthreads > 0 ? nthreads : 1; }
 
+/* The floating-point environment of the calling thread: MXCSR (rounding mode bits 13-14, flush-to-zero bit 15,
+ * denormals-are-zero bit 6).  The oracle's results are only reproducible under the default 0x1f80 (round to nearest, no
+ * FTZ / DAZ); a test harness can check that nothing in the process has changed it. */
+unsigned oracle_fp_state(void)
+{
+    unsigned csr = 0;
+    __asm__ volatile("stmxcsr %0" : "=m"(csr));
+    return csr;
+}
+
 /* ---- bench.py cpu_baseline leg: time `reps` GEMV passes over `nrows` generated rows -------- */
 double oracle_time_gemv_rows(int n, int nrows, int reps)
 {

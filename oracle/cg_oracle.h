@@ -53,6 +53,7 @@ int oracle_solve(const double *A, const double *b, double *x, int n, int max_ite
 /* Host threads that work on the row blocks of the psize logical ranks (default 1 = the serial path).  Results do
  * not depend on it: reductions over ranks are always done sequentially in rank order. */
 void oracle_set_threads(int nthreads);
+unsigned oracle_fp_state(void);   /* MXCSR of the calling thread (0x1f80 = default: round to nearest, no FTZ/DAZ) */
 
 /* Same recurrence, but A is never materialised as one block by the caller: the oracle
  * allocates psize row blocks itself with oracle_generate_lap2d_rows (used for large N). */

@@ -132,6 +132,13 @@ def solve(A, b, x0=None, max_iter=None, tol=1e-10, psize=1):
     return x, res.as_dict()
 
 
+def fp_state():
+    """MXCSR of the calling thread, exception flags masked out (0x1f80 = round to nearest, no flush-to-zero)."""
+    L = lib()
+    L.oracle_fp_state.restype = C.c_uint
+    return L.oracle_fp_state() & ~0x3f
+
+
 def set_threads(nthreads):
     """Host threads working on the logical ranks' row blocks (results do not depend on it)."""
     lib().oracle_set_threads(int(nthreads))

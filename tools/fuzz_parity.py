@@ -26,6 +26,21 @@ while time.time() - t0 < budget:
     b = O.init_source_term(n)
     if rng.integers(0, 3) == 0:
         b = rng.standard_normal(n)
+    only = os.environ.get("ONLY")          # "n,P": replay one case of a seed (the draws above are consumed as usual)
+    if only and only != "%d,%d" % (n, P):
+        cases += 1
+        continue
+    if only:
+        # diagnostics for a replayed case: the same problem through other forms of the path
+        xo, ro = O.solve(A, b, x0, iters, 0.0, P)
+        for (bd, v, PP) in ((banded, variant, P), (banded, 30001 if banded else 0, P), (False, 0, P), (banded, variant, 1), (banded, variant, 2), (banded, variant, 4)):
+            with pkg.CGSolver(comm_mode=pkg.COMM_LOOPBACK if PP > 1 else pkg.COMM_SELF, nranks=PP, gemv_variant=v, check_every=every,
+                              matrix_format=pkg.MATRIX_BANDED if bd else pkg.MATRIX_DENSE) as s:
+                s.generate_lap2d_matrix(n); s.set_source_term(b); s.set_max_iter(iters); s.tolerance(0.0)
+                x = x0.copy(); r = s.solve(x)
+            xo2, ro2 = O.solve(A, b, x0, iters, 0.0, PP)
+            print("banded=%d variant=%d P=%d: err vs oracle(P) %.3e  res %r / %r  x0 zero=%s" % (bd, v, PP, np.linalg.norm(x - xo2) / np.linalg.norm(xo2), r["residual_prev"], ro2["residual_prev"], not x0.any()), flush=True)
+        sys.exit(0)
     with pkg.CGSolver(comm_mode=pkg.COMM_LOOPBACK if P > 1 else pkg.COMM_SELF, nranks=P, gemv_variant=variant,
                       check_every=every, matrix_format=pkg.MATRIX_BANDED if banded else pkg.MATRIX_DENSE) as s:
         s.generate_lap2d_matrix(n); s.set_source_term(b); s.set_max_iter(iters); s.tolerance(0.0)
@@ -39,6 +54,10 @@ while time.time() - t0 < budget:
     worst = max(worst, err if np.isfinite(err) else 0.0)
     cases += 1
     if not ok:
+        # which side moved?  the oracle again (same inputs, same process), its floating-point environment, the GPU again
+        xo3, ro3 = O.solve(A, b, x0, iters, 0.0, P)
+        print("oracle again: residual %r (first %r), |dx oracle-oracle| %.3e, MXCSR 0x%x, case %d" % (
+            ro3["residual_prev"], ro["residual_prev"], np.linalg.norm(xo3 - xo), O.fp_state(), cases), flush=True)
         print("MISMATCH n=%d P=%d banded=%d variant=%d iters=%d every=%d err=%.3e res %r vs %r" %
               (n, P, banded, variant, iters, every, err, r["residual_prev"], ro["residual_prev"]), flush=True)
         sys.exit(1)
