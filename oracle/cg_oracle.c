@@ -29,6 +29,19 @@ static double now_s(void)
 }
 
 /* ---- code/MPI/cg.cc:236-268 : partition_matrix --------------------------------------- */
+/* The oracle computes under the default floating-point environment whatever the host process has done to the calling
+ * thread's MXCSR (a library loaded with -ffast-math start-up code sets flush-to-zero; anything may change the rounding
+ * mode): round to nearest, no FTZ / DAZ, exceptions masked.  fp_enter returns the caller's MXCSR, fp_leave puts it back.
+ * (Threads OpenMP creates start with the default anyway.) */
+static unsigned fp_enter(void)
+{
+    unsigned saved = 0, dflt = 0x1f80;
+    __asm__ volatile("stmxcsr %0" : "=m"(saved));
+    __asm__ volatile("ldmxcsr %0" : : "m"(dflt));
+    return saved;
+}
+static void fp_leave(unsigned saved) { __asm__ volatile("ldmxcsr %0" : : "m"(saved)); }
+
 void oracle_partition(int N, int psize, int *start_rows, int *num_rows)
 {
     if (psize == 1) {               /* cg.cc:248-252 */
@@ -277,7 +290,7 @@ static void free_rank_vectors(rank_state *s)
     free(s->r); free(s->x); free(s->Ap); free(s->p); free(s->tmp);
 }
 
-int oracle_solve(const double *A, const double *b, double *x, int n, int max_iter, double tol,
+static int oracle_solve_impl(const double *A, const double *b, double *x, int n, int max_iter, double tol,
                  int psize, oracle_result *res)
 {
     if (!A || !b || !x || n <= 0 || psize <= 0) return -2;
@@ -299,7 +312,7 @@ int oracle_solve(const double *A, const double *b, double *x, int n, int max_ite
     return rc;
 }
 
-int oracle_solve_lap2d(int n, int max_iter, double tol, int psize, double *x, oracle_result *res)
+static int oracle_solve_lap2d_impl(int n, int max_iter, double tol, int psize, double *x, oracle_result *res)
 {
     if (!x || n <= 0 || psize <= 0) return -2;
     int *start = (int *)malloc(sizeof(int) * (size_t)psize);
@@ -327,7 +340,7 @@ int oracle_solve_lap2d(int n, int max_iter, double tol, int psize, double *x, or
     return rc;
 }
 
-int oracle_solve_lap2d_banded(int n, int max_iter, double tol, int psize, double *x, oracle_result *res)
+static int oracle_solve_lap2d_banded_impl(int n, int max_iter, double tol, int psize, double *x, oracle_result *res)
 {
     if (!x || n <= 0 || psize <= 0) return -2;
     int *start = (int *)malloc(sizeof(int) * (size_t)psize);
@@ -414,4 +427,29 @@ double oracle_time_gemv_rows(int n, int nrows, int reps)
     double t1 = now_s();
     free(A); free(p); free(y);
     return t1 - t0;
+}
+
+int oracle_solve(const double *A, const double *b, double *x, int n, int max_iter, double tol,
+                 int psize, oracle_result *res)
+{
+    const unsigned fp = fp_enter();
+    const int rc = oracle_solve_impl(A, b, x, n, max_iter, tol, psize, res);
+    fp_leave(fp);
+    return rc;
+}
+
+int oracle_solve_lap2d(int n, int max_iter, double tol, int psize, double *x, oracle_result *res)
+{
+    const unsigned fp = fp_enter();
+    const int rc = oracle_solve_lap2d_impl(n, max_iter, tol, psize, x, res);
+    fp_leave(fp);
+    return rc;
+}
+
+int oracle_solve_lap2d_banded(int n, int max_iter, double tol, int psize, double *x, oracle_result *res)
+{
+    const unsigned fp = fp_enter();
+    const int rc = oracle_solve_lap2d_banded_impl(n, max_iter, tol, psize, x, res);
+    fp_leave(fp);
+    return rc;
 }

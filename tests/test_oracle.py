@@ -270,3 +270,26 @@ def test_banded_twin_at_the_pinned_large_sizes(oracle, reference_probe):
         assert abs(r["x_norm"] - row["x_norm"]) <= 1e-12 * row["x_norm"]
         for i, v in row["x_samples"].items():
             assert abs(x[int(i)] - v) <= 1e-12 * abs(v), i
+
+
+def test_oracle_solves_do_not_depend_on_the_callers_floating_point_environment(oracle):
+    """The checker must give the same bits whatever the host process has done to the calling thread's MXCSR (a library
+    loaded with fast-math start-up code sets flush-to-zero, anything may switch the rounding mode): the solve entry points
+    run under round-to-nearest without FTZ / DAZ and put the caller's environment back."""
+    import ctypes
+    libm = ctypes.CDLL("libm.so.6")
+    FE_TONEAREST, FE_TOWARDZERO = 0x000, 0xc00
+    n, it, p = 600, 40, 3
+    x_ref, r_ref = oracle.solve_lap2d(n, it, 0.0, p)
+    assert oracle.fp_state() == 0x1f80
+    try:
+        assert libm.fesetround(FE_TOWARDZERO) == 0
+        assert oracle.fp_state() != 0x1f80                      # the thread really computes toward zero now
+        x, r = oracle.solve_lap2d(n, it, 0.0, p)
+        xb, rb = oracle.solve_lap2d_banded(n, it, 0.0, p)
+        assert libm.fegetround() == FE_TOWARDZERO               # the caller's environment is put back
+    finally:
+        libm.fesetround(FE_TONEAREST)
+    assert np.array_equal(x, x_ref) and r["residual_prev"] == r_ref["residual_prev"] and r["x_norm"] == r_ref["x_norm"]
+    xb_ref, rb_ref = oracle.solve_lap2d_banded(n, it, 0.0, p)
+    assert np.array_equal(xb, xb_ref) and rb["residual_prev"] == rb_ref["residual_prev"]
