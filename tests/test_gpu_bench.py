@@ -45,8 +45,11 @@ def test_bench_line_contract(gpu_pkg):
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
     assert "error" not in d
     # roofline.traffic: by default counters of THIS box (two rocprofv3 --pmc child passes of the same workload), per launch
-    assert rf["traffic_source"].startswith("LIVE"), rf.get("traffic_live_note")
-    assert 0.9 < rf["traffic_over_algorithmic"] < 1.2 and abs(rf["traffic"] - rf["traffic_over_algorithmic"] * rf["bytes_per_launch"]) < 1.0
+    if rf["traffic_source"].startswith("LIVE"):
+        assert 0.9 < rf["traffic_over_algorithmic"] < 1.2 and abs(rf["traffic"] - rf["traffic_over_algorithmic"] * rf["bytes_per_launch"]) < 1.0
+    else:
+        # a box that cannot start the profiler (no rocprofv3, no counter access): the line says why and falls back
+        assert rf["traffic_live_note"] and rf["traffic"] is None
     assert rf["traffic_committed"] is None          # no committed row for N = 4096
 
 
