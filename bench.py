@@ -260,6 +260,8 @@ class Bench:
         self.prewarm_iterations = {}
         self.gpu_work_s = 0.0          # seconds of solver work this rank put on its GPU (pre-warm, calibration, timed run, window)
         self.gpu_iterations = 0
+        self.update_samples = []       # durations (ms) of the event-timed update kernels of the most recent run()
+        self.rccl_nranks = None        # ncclCommCount of the RCCL candidate (min over ranks), if one was built
 
     # ---- plumbing ------------------------------------------------------------------------------------
     def log(self, msg):
@@ -591,7 +593,7 @@ class Bench:
         my_rows = counts[rank]
         k1_rows = self.gather_rows([my_rows, res["gemv_launches"], res["gemv_discarded"], res["gemv_ms_min"],
                                     res["gemv_ms_median"], res["gemv_ms_avg"], res["gemv_ms_max"]])
-        us = sorted(float(v) for v in getattr(self, "update_samples", []))
+        us = sorted(float(v) for v in self.update_samples)
         upd_rows = self.gather_rows([float(len(us)), us[0] if us else 0.0, us[len(us) // 2] if us else 0.0, us[-1] if us else 0.0])
         dev_ms = self.max_over_ranks(res.get("steps_device_ms", 0.0))
         info = solver.comm_info()
