@@ -272,7 +272,7 @@ def test_bench_self_launch_weak_mode_two_ranks(gpu_pkg, oracle):
 def test_bench_keeps_the_measurement_when_an_extra_hangs(gpu_pkg):
     """The CPU baseline (or a live counter pass) never comes back: the watchdog prints the line that was complete before it --
     value, roofline, everything measured -- with a note, and the exit code stays 0."""
-    r = subprocess.run([sys.executable, BENCH, "--steps", "20", "--warmup", "5", "--matrix-size", "4096", "--no-live-pmc", "--watchdog", "30"],
+    r = subprocess.run([sys.executable, BENCH, "--steps", "20", "--warmup", "5", "--matrix-size", "4096", "--no-live-pmc", "--watchdog", "18"],
                        capture_output=True, text=True, timeout=300, env=dict(os.environ, CGX_BENCH_TEST_HANG="extra:cpu baseline"))
     d = one_line(r.stdout)
     assert r.returncode == 0, r.stderr[-2000:]
