@@ -104,3 +104,25 @@ def test_parser_header_errors(pkg, tmp_path):
     with pytest.raises(pkg.CgxError) as e:
         pkg.cgx.parse_matrix_market(str(tmp_path / "missing.mtx"))
     assert e.value.status == 2 and "Could not open matrix" in str(e.value)
+
+
+@pytest.mark.parametrize("threads", [1, -3, -16])
+def test_parser_file_ending_exactly_at_a_page_boundary_without_a_newline(pkg, tmp_path, threads):
+    """The body is parsed from the mapped file: a file whose size is a whole number of pages and whose last token runs to the
+    very last byte must not be read past its end (nothing terminates a token there but the end of the mapping)."""
+    page = os.sysconf("SC_PAGE_SIZE")
+    head = "%%MatrixMarket matrix coordinate real general\n"
+    n, nz = 9999, 2000
+    rows = ["%d %d %.17g" % (1 + (7 * k) % n, 1 + (13 * k) % n, 0.5 + k) for k in range(nz)]
+    body = "\n".join(rows)
+    size_line = "%d %d %d\n" % (n, n, nz)
+    total = len(head) + len(size_line) + len(body)
+    pad = (-total) % page                       # comment line of exactly the missing length (>= 2: '%' and '\n')
+    if pad < 2:
+        pad += page
+    text = head + "%" + "c" * (pad - 2) + "\n" + size_line + body
+    assert len(text) % page == 0 and not text.endswith("\n")
+    f = tmp_path / "page.mtx"
+    f.write_text(text)
+    m, n2, sym, I, J, a = pkg.cgx.parse_matrix_market(str(f), threads)
+    assert (m, n2, len(a)) == (n, n, nz) and a[-1] == 0.5 + (nz - 1) and I[-1] == (7 * (nz - 1)) % n and J[0] == 0
