@@ -135,6 +135,15 @@ inline bool fault_due(cgx_ctx *ctx)
     return false;
 }
 
+// An early return must not leave work of this context in flight: several entry points enqueue asynchronous copies into
+// their own locals (a result struct on the stack, a scratch vector) and synchronise further down; if a call in between --
+// or, under fault injection, the synchronisation itself -- fails, the copy would land in memory that is gone.  So the
+// failure path drains the context's stream first (best effort; the error that is reported is the original one).
+inline void quiesce(cgx_ctx *ctx)
+{
+    if (ctx && ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+}
+
 #define HIP_TRY(ctx, call)                                                                              \
     do {                                                                                                \
         hipError_t e_ = cgxi::fault_due(ctx) ? hipErrorUnknown : (call);                                \
@@ -142,6 +151,7 @@ inline bool fault_due(cgx_ctx *ctx)
             cgx_status st_ = (e_ == hipErrorOutOfMemory) ? CGX_ERR_OOM                                  \
                              : (e_ == hipErrorNoDevice || e_ == hipErrorInvalidDevice) ? CGX_ERR_NO_DEVICE \
                                                                                        : CGX_ERR_HIP;   \
+            cgxi::quiesce(ctx);                                                                         \
             return fail(ctx, st_, std::string(#call) + ": " + hipGetErrorString(e_));                   \
         }                                                                                               \
     } while (0)
@@ -149,8 +159,10 @@ inline bool fault_due(cgx_ctx *ctx)
 #define NCCL_TRY(ctx, call)                                                                             \
     do {                                                                                                \
         ncclResult_t r_ = (call);                                                                       \
-        if (r_ != ncclSuccess)                                                                          \
+        if (r_ != ncclSuccess) {                                                                        \
+            cgxi::quiesce(ctx);                                                                         \
             return fail(ctx, CGX_ERR_RCCL, std::string(#call) + ": " + (ctx)->rccl->GetErrorString(r_)); \
+        }                                                                                               \
     } while (0)
 
 #define CGX_TRY(call)                      \
