@@ -1,6 +1,6 @@
 """Worker for tests/test_gpu_p2p.py: one OS process per rank, all on ONE GPU, exchanging through the
 CGX_COMM_P2P mailboxes (hipIpc) -- the direct-xGMI transport rehearsed without a multi-GPU node.
-Control plane (handle exchange, verdict) over gloo.  argv: n max_iter out.json [variant] [separate_exchange 0|1] [tagged 0|1]"""
+Control plane (handle exchange, verdict) over gloo.  argv: n max_iter out.json [variant] [separate_exchange 0|1] [tagged 0|1] [banded 0|1]"""
 import json
 import os
 import sys
@@ -19,12 +19,14 @@ def main():
     variant = int(sys.argv[4]) if len(sys.argv) > 4 else 0
     separate = len(sys.argv) > 5 and sys.argv[5] == "1"
     tagged = len(sys.argv) > 6 and sys.argv[6] == "1"
+    banded = len(sys.argv) > 7 and sys.argv[7] == "1"      # opt-in banded storage: sizes no dense block can have
     dist.init_process_group(backend="gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     assert torch.cuda.is_available()
     pkg = g.load_package()
     s = pkg.CGSolver(comm_mode=pkg.COMM_P2P, nranks=world, rank=rank, device=0, gemv_variant=variant, p2p_timeout_ms=20000,
-                     p2p_separate_exchange=separate, p2p_tagged=tagged)
+                     p2p_separate_exchange=separate, p2p_tagged=tagged,
+                     matrix_format=pkg.MATRIX_BANDED if banded else pkg.MATRIX_DENSE)
     mine = torch.tensor(list(s.p2p_export()), dtype=torch.uint8)
     allh = [torch.zeros_like(mine) for _ in range(world)]
     dist.all_gather(allh, mine)
@@ -60,7 +62,7 @@ def main():
                    "seconds_solve": res["seconds_solve"]}, open(out_path, "w"))
     elif rank == 0:
         O = g.load_oracle()
-        xo, ro = O.solve_lap2d(n, max_iter, tol, world)
+        xo, ro = (O.solve_lap2d_banded if banded else O.solve_lap2d)(n, max_iter, tol, world)
         json.dump({"world": world, "n": n, "selftest_ok": bool(ok), "ranks_agree": bool(same_x and same_sc),
                    "k": res["iterations"], "k_oracle": ro["iterations"], "converged": res["converged"],
                    "dx": float(np.linalg.norm(x - xo) / np.linalg.norm(xo)),

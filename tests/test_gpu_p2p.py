@@ -12,11 +12,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run(world, n, max_iter, tmp_path, port, variant=0, separate=0, tagged=0):
+def run(world, n, max_iter, tmp_path, port, variant=0, separate=0, tagged=0, banded=0):
     out = tmp_path / ("p2p_%d_%d.json" % (world, n))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "tests", "p2p_worker.py"), str(n), str(max_iter), str(out), str(variant), str(separate), str(tagged)]
+           os.path.join(ROOT, "tests", "p2p_worker.py"), str(n), str(max_iter), str(out), str(variant), str(separate), str(tagged), str(banded)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=420,
                        env=dict(os.environ, OMP_NUM_THREADS="1", MASTER_ADDR="127.0.0.1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
@@ -55,6 +55,15 @@ def test_p2p_processes_with_a_column_split_k1(tmp_path, world, n, max_iter, port
     vectors, which the fused update adds up on the fly (pushers and own rows, same order) -- real processes over IPC."""
     v = run(world, n, max_iter, tmp_path, port, variant=variant, separate=separate)
     _check_p2p(v, n)
+
+
+@pytest.mark.parametrize("tagged,port", [(0, 29741), (1, 29742)])
+def test_p2p_more_chunk_pairs_than_threads(tmp_path, tagged, port):
+    """200 000 rows on two ranks (banded storage: no dense block of that size exists): 196 chunks per rank, 392 (peer, chunk)
+    pairs -- more than the 256 threads of a workgroup, so every thread of the fused update polls and folds more than one
+    partial, and the pushers take several pairs each.  Both forms of the exchange, against the oracle's on-the-fly twin."""
+    v = run(2, 200000, 30, tmp_path, port, tagged=tagged, banded=1)
+    _check_p2p(v, 200000)
 
 
 def _check_p2p(v, n):
