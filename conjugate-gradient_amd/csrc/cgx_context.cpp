@@ -392,7 +392,7 @@ cgx_status cgx_create(cgx_ctx **out, const cgx_config *cfg_in)
         }
     }
     if (cfg.comm_mode == CGX_COMM_P2P) {
-        ctx->mailbox_bytes = (size_t)(cfg.p2p_mailbox_kib > 0 ? cfg.p2p_mailbox_kib : 4096) * 1024;
+        ctx->mailbox_bytes = (size_t)(cfg.p2p_mailbox_kib > 0 ? cfg.p2p_mailbox_kib : 16384) * 1024;   // 16 MiB: any problem the fused update takes (262 144 rows), also as tagged words
         ctx->p2p_timeout_ticks = (long long)(cfg.p2p_timeout_ms > 0 ? cfg.p2p_timeout_ms : 5000) * 100000LL;   // 100 MHz
         // fine-grained: stores from peers and system-scope atomics are coherent without a kernel boundary
         if (hipExtMallocWithFlags(reinterpret_cast<void **>(&ctx->mailbox), ctx->mailbox_bytes, hipDeviceMallocFinegrained) != hipSuccess ||

@@ -84,7 +84,7 @@ typedef struct cgx_config {
                                  on the same launches as K1 (needs profile_gemv > 0): on a multi-GPU run its duration holds the
                                  wait for the peers, i.e. the cost of the exchange (cgx_get_update_samples).  Default 0: a
                                  timed dispatch costs ~5 us of stream time.  (The field was reserved0 before round 3.) */
-    int  p2p_mailbox_kib;     /* CGX_COMM_P2P: mailbox size in KiB (0 = 4096)               */
+    int  p2p_mailbox_kib;     /* CGX_COMM_P2P: mailbox size in KiB (0 = 16384)               */
     int  p2p_timeout_ms;      /* CGX_COMM_P2P: bound of every in-kernel wait (0 = 5000)     */
     int  p2p_separate_exchange; /* CGX_COMM_P2P: 1 = exchange in its own kernel between K1 and K3 (default 0: folded into K3) */
     int  matrix_format;       /* cgx_matrix_format; 0 = dense = the reference's storage     */
