@@ -178,3 +178,25 @@ def test_exchange_through_host_memory_gives_the_same_bits(oracle, tagged):
     xo, ro = oracle.solve_lap2d(n, iters, 0.0, 1)
     assert np.linalg.norm(xh - xo) <= 1e-12 * np.linalg.norm(xo)
     print("loop seconds: device mailbox %.4f, host mailbox %.4f" % (rd["seconds_loop"], rh["seconds_loop"]))
+
+
+def test_both_forms_of_the_fused_exchange_give_the_same_bits():
+    """Flag words and tagged words hand over the same chunks, reduced by the same device functions in the same order: the solves
+    are bit-identical (one rank over its own mailbox; the multi-process tests compare each form with the oracle)."""
+    import numpy as np
+    import torch  # noqa: F401 -- before libcgx
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    pkg = g.load_package()
+    n, iters = 5000, 60
+    out = []
+    for tagged in (False, True):
+        with pkg.CGSolver(comm_mode=pkg.COMM_P2P, nranks=1, p2p_tagged=tagged) as s:
+            s.generate_lap2d_matrix(n)
+            s.set_max_iter(iters)
+            s.tolerance(0.0)
+            s.init_source_term(1.0 / n)
+            x = np.zeros(n)
+            out.append((x, s.solve(x)))
+    (xf, rf), (xt, rt) = out
+    assert np.array_equal(xf, xt) and rf["residual_prev"] == rt["residual_prev"] and rf["x_norm"] == rt["x_norm"]
