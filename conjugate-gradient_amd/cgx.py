@@ -30,7 +30,8 @@ EXPORTS = [
     "cgx_get_update_samples",
     "cgx_probe_gemv", "cgx_probe_time_gemv", "cgx_probe_vector_ops", "cgx_probe_get_matrix_rows",
     "cgx_probe_get_source_term", "cgx_probe_set_fault_after", "cgx_probe_set_resident_limit",
-    "cgx_probe_parse_matrix_market", "cgx_probe_p2p_mailbox_to_host",
+    "cgx_probe_parse_matrix_market", "cgx_probe_p2p_mailbox_to_host", "cgx_probe_fill_matrix_hash",
+    "cgx_probe_set_p2p_epoch", "cgx_probe_get_p2p_epoch",
 ]
 
 
@@ -132,6 +133,9 @@ def lib():
         L.cgx_probe_set_fault_after.argtypes = [vp, C.c_int]
         L.cgx_probe_set_resident_limit.argtypes = [vp, C.c_int]
         L.cgx_probe_p2p_mailbox_to_host.argtypes = [vp]
+        L.cgx_probe_fill_matrix_hash.argtypes = [vp, C.c_ulonglong, C.c_int, C.c_double]
+        L.cgx_probe_set_p2p_epoch.argtypes = [vp, C.c_int, C.c_ulonglong]
+        L.cgx_probe_get_p2p_epoch.argtypes = [vp, C.c_int, C.POINTER(C.c_ulonglong)]
         L.cgx_probe_parse_matrix_market.argtypes = [C.c_char_p, C.c_int, ip, ip, ip, ip, ip, ip, dp, C.c_long, C.c_char_p, C.c_int]
         for name in EXPORTS:
             fn = getattr(L, name)
@@ -392,9 +396,23 @@ class CGSolver:
         """Test hook: the mailbox of a one-rank P2P context moves to pinned coherent host memory (exchange over PCIe)."""
         self._check(lib().cgx_probe_p2p_mailbox_to_host(self._h))
 
+    def _set_p2p_epoch(self, chan, value):
+        """Test hook: move the epoch counter of a mailbox channel forward (same call on every rank, between two solves)."""
+        self._check(lib().cgx_probe_set_p2p_epoch(self._h, int(chan), int(value)))
+
+    def _p2p_epoch(self, chan):
+        v = C.c_ulonglong()
+        self._check(lib().cgx_probe_get_p2p_epoch(self._h, int(chan), C.byref(v)))
+        return v.value
+
     def _set_resident_limit(self, workgroups):
         """Test hook: bound of co-resident workgroups the fused P2P update may assume (0 = ask the runtime)."""
         lib().cgx_probe_set_resident_limit(self._h, int(workgroups))
+
+    def probe_fill_matrix_hash(self, seed, symmetric=False, diag=0.0):
+        """Test probe: the dense row blocks of the current problem overwritten on the device with the counter-based hash matrix
+        (every element a different number in [-1, 1); the tests rebuild any row on the host from the same definition)."""
+        self._check(lib().cgx_probe_fill_matrix_hash(self._h, int(seed), 1 if symmetric else 0, float(diag)))
 
     def probe_source_term(self, local_shard=0):
         """The device copy of b (n doubles) of a local shard."""

@@ -96,6 +96,21 @@ long default_lda(const cgx_ctx *ctx, int n)
     return lda;
 }
 
+// Tagged words: zero this rank's own channel-1 slots of the layout just established (enqueued on the context's stream).  What
+// a tagged reader may find in a position is then a zero or a tagged word of an earlier epoch of THIS layout, never something
+// a different geometry (or the self-test) left there.  Safe without a launcher barrier: nothing of the previous layout is in
+// flight towards this mailbox any more (the last exchange of a solve and of the self-test is on channel 2: a rank finishes it
+// only after every peer has pushed its channel-2 data, which a peer does, in stream order, after its last channel-1 kernel),
+// and a peer that is ahead can push tagged words of the NEW layout only after it has completed a plain all-gather of that
+// layout (solve_begin's, or the first half of the self-test) -- which needs this rank's contribution, enqueued behind this
+// memset on the same stream.  A peer's plain pushes of the new layout land in channel 0 / 2, which are not touched here.
+static cgx_status scrub_tagged_region(cgx_ctx *ctx)
+{
+    const size_t bytes = (size_t)(2L * ctx->nranks * ctx->mv.slot_bytes[1]);
+    HIP_TRY(ctx, hipMemsetAsync(ctx->mailbox + ctx->mv.data_off[1], 0, bytes, ctx->stream));
+    return CGX_OK;
+}
+
 // Allocate the shards for an n x n problem (matrix contents are filled by the caller).
 cgx_status setup_problem(cgx_ctx *ctx, int n)
 {
@@ -189,9 +204,19 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
         ctx->mv.data_off[1] = off;
         ctx->mv.slot_bytes[1] = slot[1];
         off += 2L * ctx->nranks * slot[1];
+        if (ctx->mv.tagged) {
+            // Tagged words: the plain-double all-gathers of the set-up and verification phases (gather_segments: the initial
+            // Ap, the final x) get a slot region of their own behind the tagged one -- channel 0, with its own flag words and
+            // epoch counter -- so that no plain double is ever stored where a tagged reader polls (cgx_kernels.hip "Tagged words").
+            ctx->mv.data_off[0] = off;
+            ctx->mv.slot_bytes[0] = ((long)(ctx->seg_Sr + ctx->npart + 1) * 8 + 15) / 16 * 16;
+            off += 2L * ctx->nranks * ctx->mv.slot_bytes[0];
+        }
         if ((size_t)off > ctx->mailbox_bytes)
             return fail(ctx, CGX_ERR_P2P, "mailbox too small for this problem: need " + std::to_string(off) +
                                               " bytes (raise cgx_config.p2p_mailbox_kib)");
+        if (ctx->mv.tagged)   // a freshly laid out tagged region holds zeros only (no tag is 0); see scrub_tagged_region
+            CGX_TRY(scrub_tagged_region(ctx));
     }
     const int seg_tail = (ctx->npart + 1 + 1) / 2 * 2;   // npart partials + 1 slot for a rank's folded sum, even
     ctx->seg_S = ctx->seg_Sr + seg_tail;
@@ -502,10 +527,22 @@ cgx_status cgx_p2p_selftest(cgx_ctx *ctx, int rounds, int *ok)
         cgx::MailboxView saved;
         ~RestoreView() { c->mv = saved; }
     } restore{ctx, ctx->mv};
+    // geometry of the second half (the fused exchange on an uneven partition, two chunks per rank)
+    const int st_n_loc = 1000, st_n = P * st_n_loc + (P > 1 ? 7 : 0);       // the last rank owns 7 rows more (cg.cc:255-266)
+    const int st_Sr = (st_n - (P - 1) * st_n_loc + 1) / 2 * 2, st_cpr = cgx::chunks_per_rank(st_Sr);
+    // the plain all-gathers of the first half: channel 1 -- or, with tagged words, channel 0 behind the tagged region, exactly
+    // as a solve lays the mailbox out (no plain double is ever stored where a tagged reader polls)
+    const int plain = ctx->mv.tagged ? 0 : 1;
     ctx->mv.data_off[1] = p2p_fixed_prefix(P);
     ctx->mv.slot_bytes[1] = (long)count * 8;
-    if ((size_t)(ctx->mv.data_off[1] + 2L * P * count * 8) > ctx->mailbox_bytes)
+    if (ctx->mv.tagged) {
+        ctx->mv.slot_bytes[1] = ((long)(st_Sr + st_cpr + 1) * 16 + 15) / 16 * 16;
+        ctx->mv.data_off[0] = ctx->mv.data_off[1] + 2L * P * ctx->mv.slot_bytes[1];
+        ctx->mv.slot_bytes[0] = (long)count * 8;
+    }
+    if ((size_t)(ctx->mv.data_off[plain] + 2L * P * count * 8) > ctx->mailbox_bytes)
         return fail(ctx, CGX_ERR_P2P, "mailbox too small for the self-test");
+    if (ctx->mv.tagged) CGX_TRY(scrub_tagged_region(ctx));
     DeviceScratch scratch;
     double *dsrc = nullptr, *ddst = nullptr;
     HIP_TRY(ctx, scratch.alloc(&dsrc, (size_t)count * sizeof(double)));
@@ -516,7 +553,7 @@ cgx_status cgx_p2p_selftest(cgx_ctx *ctx, int rounds, int *ok)
         for (int i = 0; i < count; ++i) hsrc[i] = 1e6 * (me + 1) + 1e3 * r + i + 0.25;
         HIP_TRY(ctx, hipMemcpyAsync(dsrc, hsrc.data(), count * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(ddst, 0, (size_t)P * count * sizeof(double), ctx->stream));
-        CGX_TRY(p2p_allgather(ctx, 1, dsrc, count, ddst, count, 1));
+        CGX_TRY(p2p_allgather(ctx, plain, dsrc, count, ddst, count, 1));
         HIP_TRY(ctx, hipMemcpyAsync(hdst.data(), ddst, (size_t)P * count * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         if (check_p2p_error(ctx) != CGX_OK) { good = false; break; }
@@ -537,9 +574,9 @@ cgx_status cgx_p2p_selftest(cgx_ctx *ctx, int rounds, int *ok)
         if (check_p2p_error(ctx) != CGX_OK) good = false;
     }
     if (good) {
-        const int n_loc = 1000, n = P * n_loc + (P > 1 ? 7 : 0);           // the last rank owns 7 rows more (cg.cc:255-266)
+        const int n_loc = st_n_loc, n = st_n;
         const int rows = (me == P - 1) ? n - me * n_loc : n_loc, row0 = me * n_loc;
-        const int Sr = (n - (P - 1) * n_loc + 1) / 2 * 2, cpr = cgx::chunks_per_rank(Sr);
+        const int Sr = st_Sr, cpr = st_cpr;
         const int grid = cgx::update_xr_grid(n);
         ctx->mv.slot_bytes[1] = ((long)(Sr + cpr + 1) * (ctx->mv.tagged ? 16 : 8) + 15) / 16 * 16;
         if ((size_t)(ctx->mv.data_off[1] + 2L * P * ctx->mv.slot_bytes[1]) > ctx->mailbox_bytes || P * cpr > cgx::kMaxChunkFlags)

@@ -124,6 +124,34 @@ hipError_t launch_debug_norms(int count, const double *Ax, const double *b, cons
 // generate_lap2d_matrix (cg.cc:159-188) for rows [row0,row0+rows) straight into device memory; pad columns = 0.
 hipError_t launch_generate_lap2d(double *A, long lda, int size, int row0, int rows, hipStream_t s);
 
+// ---- dense, incompressible test data (TEST PROBE, cgx_probe_fill_matrix_hash; not a reference function) -------------
+// The reference's generator leaves 5 non-zeros per row (cg.cc:178-186): at N = 32768 the matrix K1 streams is 99.985 % zeros.
+// Its GEMV is a general dense dgemv (cg.cc:101-102), so parity and rate are also shown on a block in which every element is
+// a different number with a full random mantissa: element (i, j) is a pure function of (seed, i, j) -- a counter-based
+// hash, the splitmix64 finaliser -- so the device fills 8 GiB in place and the parity checker (which restates the
+// same three lines) rebuilds any row on the host without an n x n copy.  Every step is exact in fp64, so host and device
+// agree bit for bit: (h >> 11) is a 53-bit integer, * 2^-52 lands in [0, 2), - 1 in [-1, 1).
+__host__ __device__ inline unsigned long long hash_mix64(unsigned long long z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// symmetric: (i, j) and (j, i) give the same value.  diag != 0: A(i,i) = diag (with symmetric and diag above the spectral
+// radius ~ 2 sqrt(n/3) of the off-diagonal part the block is SPD, so that CG runs on it for hundreds of iterations).
+__host__ __device__ inline double hash_entry(unsigned long long seed_mixed, int symmetric, double diag, long i, long j)
+{
+    if (i == j && diag != 0.0) return diag;
+    const unsigned long long a = (symmetric && j < i) ? (unsigned long long)j : (unsigned long long)i;
+    const unsigned long long b = (symmetric && j < i) ? (unsigned long long)i : (unsigned long long)j;
+    const unsigned long long h = hash_mix64(seed_mixed ^ ((a << 32) | b));
+    return (double)(h >> 11) * 0x1.0p-52 - 1.0;
+}
+// rows [row0, row0+rows) of the n x n hash matrix into a dense block at pitch lda; pad columns = 0.
+hipError_t launch_fill_hash(double *A, long lda, int n, int row0, int rows, unsigned long long seed, int symmetric, double diag,
+                            hipStream_t s);
+
 // Matrix::read (matrix.cc:12-21) on the device, for the WHOLE entry list of the file in file order (0-based I, J;
 // `sym`: entry z also assigns (J,I) right after (I,J), matrix.cc:18-20).  Entries outside rows [row0,row0+rows) are
 // skipped.  A later assignment to the same element overrides an earlier one exactly as the sequential loop does:
@@ -170,7 +198,8 @@ hipError_t launch_dia_pack(const double *A, long lda, int n, int row0, int rows,
 //   chunk flags : kMaxChunkFlags words of 8 B, word q*cpr + c = last epoch rank q delivered chunk c of its slice on
 //                 channel 1 through the fused update kernel (k_update_xr_p2p)
 //   data  : per channel c, [2 parities][nranks] slots of slot_bytes[c]
-constexpr int kP2pChannels = 3;          // 0 = unused, 1 = [Ap slice | p.Ap] segments, 2 = DEBUG scalars
+constexpr int kP2pChannels = 3;          // 1 = [Ap slice | p.Ap] segments, 2 = DEBUG scalars; 0 = with tagged words: the plain
+                                         // all-gathers of segments (set-up / verification phases), else unused
 constexpr int kP2pFlagStride = 128;      // bytes between flag words
 constexpr int kMaxChunkFlags = 2048;     // nranks * chunks per rank <= this (262144 rows: 512 + nranks)
 struct MailboxView {

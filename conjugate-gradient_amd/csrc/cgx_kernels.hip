@@ -861,6 +861,27 @@ __global__ __launch_bounds__(256) void k_generate_lap2d(double *__restrict__ A, 
     }
 }
 
+// TEST PROBE (cgx_probe_fill_matrix_hash): the row block filled with hash_entry -- dense, incompressible data for the parity
+// and rate checks of K1 at the BASELINE sizes.  Same store pattern as the generator: one thread writes 16 B.
+__global__ __launch_bounds__(256) void k_fill_hash(double *__restrict__ A, long lda, int n, int row0, int rows,
+                                                    unsigned long long seed_mixed, int symmetric, double diag)
+{
+    const long pairs_per_row = lda / 2;
+    const long total = (long)rows * pairs_per_row;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const long lr = t / pairs_per_row;
+        const int j0 = (int)(t - lr * pairs_per_row) * 2;
+        const long i = (long)row0 + lr;
+        d2 v;
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int j = j0 + e;
+            v[e] = (j < n) ? hash_entry(seed_mixed, symmetric, diag, i, j) : 0.0;
+        }
+        *reinterpret_cast<d2 *>(A + lr * lda + j0) = v;
+    }
+}
+
 __global__ void k_loopback_gather(double *const *gathered_ptrs, const Scalars *const *scalar_ptrs, int nshards)
 {
     const int t = threadIdx.x;
@@ -1342,8 +1363,12 @@ __device__ __forceinline__ ChunkItem chunk_fetch(int pr, int cpr, const double *
 }
 
 // [chunk of Ap | its p.Ap partial] into the peer's slot, then the peer's flag word (me, chunk).
-// Release: the barrier orders every wave's stores before lane 0's system-scope release store of the flag (workgroup
-// release + barrier, then one system release: cumulative), instead of a system-scope fence in all four waves.
+// Release, the producer form of the guide (MI355X_MICROARCH.md, "Valid forms"): EVERY storing wave waits for its own stores
+// (`s_waitcnt vmcnt(0)`: the counter is per wave, and neither a barrier nor a workgroup-scope release drains it), then the
+// workgroup barrier, then lane 0: one system-scope release fence, its own vmcnt(0), and the flag as a relaxed system-scope
+// store.  (Round 3 had only the barrier and a release STORE by lane 0: in the ISA waves 1-3 went from their
+// global_store_dwordx4 straight to s_barrier, so over xGMI the flag could have passed their part of the chunk -- the
+// one-GPU self-test cannot see that; found by review)
 __device__ __forceinline__ void chunk_publish(const MailboxView &mv, int chan, unsigned long long epoch, int cpr, int Sr,
                                               const ChunkItem &it, double *lds)
 {
@@ -1352,10 +1377,14 @@ __device__ __forceinline__ void chunk_publish(const MailboxView &mv, int chan, u
     double *out = reinterpret_cast<double *>(mv.base[it.peer] + mv.data_off[chan] + ((long)par * P + me) * mv.slot_bytes[chan]);
     if (it.row < Sr) *reinterpret_cast<d2 *>(out + it.row) = it.a;
     if (threadIdx.x == 0) out[Sr + it.c] = d;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // this wave's stores have been acknowledged
     __syncthreads();
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                 // system scope
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __hip_atomic_store(reinterpret_cast<unsigned long long *>(mv.base[it.peer] + mv.cflag_off) + (me * cpr + it.c), epoch,
-                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 // Lane f waits for flag word f = (source rank, chunk) of MY mailbox (bounded by the 100 MHz wall clock), then ONE
@@ -1474,10 +1503,24 @@ __global__ __launch_bounds__(256) void k_update_xr_p2p(int n, int rows, int row0
 // epoch in a word knows that the word's other half belongs to the same store (8-byte atomics are single-copy atomic), and
 // it needs nothing else: no word depends on the order in which any other word arrives, so there is no release, no flag,
 // no acquire, and no barrier between "the data is there" and "use it" -- the chain is store -> (xGMI) -> the poll that
-// hits.  A slot still holds the words of epoch e-2 until they are overwritten: the tag is compared for equality.  The
-// mailbox is zero-filled when it is created; no tag of the first 4.29e9 epochs is 0.
+// hits.  A slot still holds the words of epoch e-2 until they are overwritten: the tag is compared for equality.
+// What a tagged slot can hold, and why none of it passes for the current epoch (round 4):
+//   * zeros -- the mailbox is zero-filled when it is created, and the tagged region is zero-filled again whenever it is laid
+//     out anew (a new problem geometry, the self-test): p2p_tag() is never 0;
+//   * tagged words of epoch e-2, e-4, ... of the SAME layout -- every position a reader looks at is rewritten in every
+//     epoch of its parity, so the newest stale tag is that of e-2, and p2p_tag(e) != p2p_tag(e-2) for every e;
+//   * nothing else: the plain-double all-gathers of the set-up and verification phases (k_mailbox_allgather: x0 / x /
+//     the initial Ap) have a slot region and an epoch counter of their own in tagged mode (channel 0), so no plain double is
+//     ever stored where a tagged reader polls.  (Round 3 shared channel 1 and relied on "no finite double looks like a tag
+//     during the first 2^19 epochs of a context".)
 // Twice the bytes on the wire (64 KiB per rank at N = 32768): irrelevant for a latency-bound exchange.
 // ------------------------------------------------------------------------------------------------
+// The tag of an epoch: 1 + (epoch mod (2^32 - 1)), i.e. 1 ... 2^32 - 1, never 0; consecutive epochs of one parity (e-2, e)
+// always differ, and two epochs share a tag only 2^32 - 1 apart.
+__device__ __forceinline__ unsigned p2p_tag(unsigned long long epoch)
+{
+    return (unsigned)(epoch % 0xFFFFFFFFull) + 1u;
+}
 // Both words of one double leave as ONE 16-byte store with the system-scope write-through bits (what the two relaxed 8-byte
 // atomic stores of the definition compile to, `global_store_dwordx2 ... sc0 sc1`, as one instruction and one request: over
 // xGMI a request is a packet, and 8-byte packets cost 2.7x the time per byte of 16-byte ones, measured for sc1 stores in the
@@ -1527,11 +1570,7 @@ __global__ __launch_bounds__(256) void k_update_xr_p2p_tagged(int n, int rows, i
 {
     __shared__ double lds[4];
     const int tid = threadIdx.x, P = mv.nranks, me = mv.rank;
-    // The tag is the epoch's low 32 bits, XORed with the upper half of a quiet NaN: a bijection (two epochs collide only 2^32
-    // apart, and a position is rewritten every second epoch), and for the first 2^19 epochs of a context no finite double
-    // that another kernel may have left in the slot (the mailbox all-gather of the set-up phases stores plain doubles
-    // there) can look like a tagged word of the current epoch.
-    const unsigned tag = (unsigned)epoch ^ 0xFFF80000u;
+    const unsigned tag = p2p_tag(epoch);
     int done = 0;
     double rsold = 0.0, r_i = 0.0, p_i = 0.0, x_i = 0.0;
     const int had_err = __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2131,6 +2170,16 @@ hipError_t launch_generate_lap2d(double *A, long lda, int size, int row0, int ro
     long total = (long)rows * (lda / 2);
     int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
     hipLaunchKernelGGL(k_generate_lap2d, dim3(grid), dim3(256), 0, s, A, lda, size, row0, rows, inc);
+    return hipGetLastError();
+}
+
+hipError_t launch_fill_hash(double *A, long lda, int n, int row0, int rows, unsigned long long seed, int symmetric, double diag,
+                            hipStream_t s)
+{
+    if (rows <= 0) return hipSuccess;
+    const long total = (long)rows * (lda / 2);
+    const int grid = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+    hipLaunchKernelGGL(k_fill_hash, dim3(grid), dim3(256), 0, s, A, lda, n, row0, rows, hash_mix64(seed), symmetric, diag);
     return hipGetLastError();
 }
 

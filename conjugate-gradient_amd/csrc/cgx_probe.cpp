@@ -182,6 +182,29 @@ cgx_status cgx_probe_p2p_mailbox_to_host(cgx_ctx *ctx)
     return CGX_OK;
 }
 
+// TEST ONLY: move the epoch counter of mailbox channel `chan` forward to `value` (the next exchange on it is value + 1), so
+// that the tests can reach the regions of the 64-bit counter a run would need ~10^9 exchanges for: the wrap of the 32-bit tag
+// of the tagged-word form (epoch = k * (2^32 - 1)), the wrap of the epoch's low 32 bits, and round 3's hazard regions (2^19,
+// 0xFFF80000).  Every rank must make the same call at a quiet point (no solve in progress; between two solves is one: the
+// last exchange of a solve is on channel 2, so every peer is done with channels 0 and 1).  Backwards is refused: the flag
+// words only ever grow.
+cgx_status cgx_probe_set_p2p_epoch(cgx_ctx *ctx, int chan, unsigned long long value)
+{
+    if (!ctx || ctx->cfg.comm_mode != CGX_COMM_P2P || chan < 0 || chan >= cgx::kP2pChannels)
+        return fail(ctx, CGX_ERR_BAD_ARG, "cgx_probe_set_p2p_epoch: a P2P context and a channel 0..2");
+    if (ctx->in_solve) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_probe_set_p2p_epoch inside begin/end");
+    if (value < ctx->p2p_epoch[chan]) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_probe_set_p2p_epoch: the epoch can only move forward");
+    ctx->p2p_epoch[chan] = value;
+    return CGX_OK;
+}
+
+cgx_status cgx_probe_get_p2p_epoch(cgx_ctx *ctx, int chan, unsigned long long *value)
+{
+    if (!ctx || !value || ctx->cfg.comm_mode != CGX_COMM_P2P || chan < 0 || chan >= cgx::kP2pChannels) return CGX_ERR_BAD_ARG;
+    *value = ctx->p2p_epoch[chan];
+    return CGX_OK;
+}
+
 cgx_status cgx_probe_set_resident_limit(cgx_ctx *ctx, int workgroups)
 {
     if (!ctx) return CGX_ERR_BAD_ARG;
@@ -197,6 +220,23 @@ cgx_status cgx_probe_get_source_term(cgx_ctx *ctx, int local_shard, double *b_ou
     if (!ctx->have_b) return fail(ctx, CGX_ERR_BAD_ARG, "no source term");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpy(b_out, ctx->shards[local_shard].b_full, (size_t)ctx->n * sizeof(double), hipMemcpyDeviceToHost));
+    return CGX_OK;
+}
+
+// TEST PROBE: overwrite the dense row block of every local shard of the CURRENT problem with the hash matrix of
+// cgx_kernels.h (hash_entry): element (i, j) = a pure function of (seed, i, j) in [-1, 1), filled on the device.  The
+// geometry (n, partition, pitch, K1 plan) stays what the problem set before it defined; b and max_iter are untouched.
+cgx_status cgx_probe_fill_matrix_hash(cgx_ctx *ctx, unsigned long long seed, int symmetric, double diag)
+{
+    if (!ctx) return CGX_ERR_BAD_ARG;
+    if (!ctx->have_matrix || ctx->shards.empty())
+        return fail(ctx, CGX_ERR_BAD_ARG, "cgx_probe_fill_matrix_hash: set a problem first (it defines n and the row blocks)");
+    if (ctx->banded) return fail(ctx, CGX_ERR_UNSUPPORTED, "cgx_probe_fill_matrix_hash: dense storage only");
+    if (ctx->in_solve) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_probe_fill_matrix_hash inside begin/end");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    for (auto &s : ctx->shards)
+        HIP_TRY(ctx, cgx::launch_fill_hash(s.A, ctx->lda, ctx->n, s.row0, s.rows, seed, symmetric ? 1 : 0, diag, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return CGX_OK;
 }
 

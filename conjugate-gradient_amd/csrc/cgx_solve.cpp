@@ -83,10 +83,11 @@ cgx_status gather_segments(cgx_ctx *ctx, bool with_tail)
                                                 hipMemcpyDeviceToDevice, ctx->stream));
         return CGX_OK;
     case CGX_COMM_P2P: {
-        // the exchange kernel folds this rank's partials and ships [Ap slice | one double]
+        // the exchange kernel folds this rank's partials and ships [Ap slice | one double].  Tagged words: these plain doubles
+        // travel on channel 0 (own slots, own flag words, own epoch counter), never through the slots a tagged reader polls.
         Shard &s = ctx->shards[0];
-        return p2p_allgather(ctx, 1, s.Ap(), ctx->seg_Sr, s.apg, ctx->seg_S, 0, ctx->seg_Sr, with_tail ? ctx->npart : 0,
-                             ctx->seg_Sr + ctx->npart);
+        return p2p_allgather(ctx, ctx->mv.tagged ? 0 : 1, s.Ap(), ctx->seg_Sr, s.apg, ctx->seg_S, 0, ctx->seg_Sr,
+                             with_tail ? ctx->npart : 0, ctx->seg_Sr + ctx->npart);
     }
     default: {
         Shard &s = ctx->shards[0];

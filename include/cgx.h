@@ -235,9 +235,22 @@ cgx_status  cgx_probe_p2p_mailbox_to_host(cgx_ctx *ctx);
  * kernel, so its grid must not exceed what the device keeps resident: occupancy x CUs, queried from the runtime when a
  * problem is set): workgroups > 0 replaces the queried bound for the problems set afterwards, 0 restores it. */
 cgx_status  cgx_probe_set_resident_limit(cgx_ctx *ctx, int workgroups);
+/* TEST ONLY: the epoch counter of mailbox channel `chan` (0 = plain segment all-gathers of a tagged-word context, 1 = the
+ * iteration's exchange, 2 = DEBUG scalars).  set: move it FORWARD to `value` (the next exchange is value + 1) so that tests
+ * reach the wrap of the tagged form's 32-bit tag and of the epoch's low 32 bits without 4e9 exchanges; every rank makes the
+ * same call between two solves.  A smaller value is refused (flag words only grow). */
+cgx_status  cgx_probe_set_p2p_epoch(cgx_ctx *ctx, int chan, unsigned long long value);
+cgx_status  cgx_probe_get_p2p_epoch(cgx_ctx *ctx, int chan, unsigned long long *value);
 /* Copy the device-resident source term of local shard `local_shard` (n doubles, what cgx_init_source_term /
  * cgx_set_source_term left in HBM) back to the host: the bit-exact check of cg.cc:230-231. */
 cgx_status  cgx_probe_get_source_term(cgx_ctx *ctx, int local_shard, double *b_out);
+/* TEST ONLY: dense, incompressible data for K1 at the BASELINE sizes.  The reference's generator leaves 5 non-zeros per row
+ * (cg.cc:178-186) while its GEMV is a general dense dgemv (cg.cc:101-102): this call overwrites the dense row block of every
+ * local shard of the CURRENT problem (set one first: it defines n, the partition and the pitch) on the device with
+ * A(i,j) = (double)(mix64(mix64(seed) ^ (i << 32 | j)) >> 11) * 2^-52 - 1 in [-1, 1), mix64 = the splitmix64 finaliser
+ * (csrc/cgx_kernels.h hash_entry; the parity tests restate it so that a checker rebuilds any row on the host).
+ * symmetric != 0: (i,j) and (j,i) share the value of (min, max).  diag != 0: A(i,i) = diag. */
+cgx_status  cgx_probe_fill_matrix_hash(cgx_ctx *ctx, unsigned long long seed, int symmetric, double diag);
 /* Copy this shard's device row block (rows x n, dense, row-major) back to the host (banded storage is expanded). */
 cgx_status  cgx_probe_get_matrix_rows(cgx_ctx *ctx, int local_shard, double *A_out, int *row0, int *rows);
 

@@ -33,6 +33,7 @@ static double now_s(void)
  * thread's MXCSR (a library loaded with -ffast-math start-up code sets flush-to-zero; anything may change the rounding
  * mode): round to nearest, no FTZ / DAZ, exceptions masked.  fp_enter returns the caller's MXCSR, fp_leave puts it back.
  * (Threads OpenMP creates start with the default anyway.) */
+#if defined(__x86_64__) || defined(__i386__)
 static unsigned fp_enter(void)
 {
     unsigned saved = 0, dflt = 0x1f80;
@@ -41,6 +42,12 @@ static unsigned fp_enter(void)
     return saved;
 }
 static void fp_leave(unsigned saved) { __asm__ volatile("ldmxcsr %0" : : "m"(saved)); }
+#else   /* any other host: the C99 environment calls; the "state" reported is then 0x1f80 iff it is the default one */
+#include <fenv.h>
+static fenv_t g_saved_env;
+static unsigned fp_enter(void) { fegetenv(&g_saved_env); fesetenv(FE_DFL_ENV); return 0; }
+static void fp_leave(unsigned saved) { (void)saved; fesetenv(&g_saved_env); }
+#endif
 
 void oracle_partition(int N, int psize, int *start_rows, int *num_rows)
 {
@@ -407,9 +414,44 @@ void oracle_set_threads(int nthreads) { g_threads = nthreads > 0 ? nthreads : 1;
  * FTZ / DAZ); a test harness can check that nothing in the process has changed it. */
 unsigned oracle_fp_state(void)
 {
+#if defined(__x86_64__) || defined(__i386__)
     unsigned csr = 0;
     __asm__ volatile("stmxcsr %0" : "=m"(csr));
     return csr;
+#else
+    return fegetround() == FE_TONEAREST ? 0x1f80u : 0u;
+#endif
+}
+
+/* ---- dense, incompressible test data: NOT a reference function ------------------------------------------------
+ * Restates csrc/cgx_kernels.h hash_entry (the device fill behind cgx_probe_fill_matrix_hash) so that the checker can
+ * rebuild any row of the hash matrix on the host: A(i,j) = (double)(mix64(mix64(seed) ^ (a << 32 | b)) >> 11) * 2^-52 - 1
+ * with (a,b) = (i,j), or (min,max) when symmetric; A(i,i) = diag when diag != 0.  mix64 is the splitmix64 finaliser.
+ * Every step is exact in fp64, so this and the device agree bit for bit.  (The reference's generator, cg.cc:178-186,
+ * leaves 5 non-zeros per row; its GEMV, cg.cc:101-102, is a general dense dgemv -- this is the data that exercises it.) */
+static unsigned long long mix64(unsigned long long z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+void oracle_hash_rows(int n, long row0, long nrows, unsigned long long seed, int symmetric, double diag, double *A)
+{
+    const unsigned long long sm = mix64(seed);
+#pragma omp parallel for schedule(static) num_threads(g_threads)
+    for (long li = 0; li < nrows; ++li) {
+        const long i = row0 + li;
+        double *row = A + (size_t)li * (size_t)n;
+        for (long j = 0; j < n; ++j) {
+            if (i == j && diag != 0.0) { row[j] = diag; continue; }
+            const unsigned long long a = (symmetric && j < i) ? (unsigned long long)j : (unsigned long long)i;
+            const unsigned long long b = (symmetric && j < i) ? (unsigned long long)i : (unsigned long long)j;
+            const unsigned long long h = mix64(sm ^ ((a << 32) | b));
+            row[j] = (double)(h >> 11) * 0x1.0p-52 - 1.0;
+        }
+    }
 }
 
 /* ---- bench.py cpu_baseline leg: time `reps` GEMV passes over `nrows` generated rows -------- */

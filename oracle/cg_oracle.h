@@ -73,6 +73,11 @@ void oracle_axpy(int n, double a, const double *x, double *y);         /* cg.cc:
  * On success *A_out is malloc'ed (m*n doubles, caller frees).  Returns 0 or a negative code. */
 int oracle_read_mtx_dense(const char *path, int *m, int *n, int *nz_stored, int *is_sym, double **A_out);
 
+/* NOT a reference function: rows [row0, row0+nrows) of the n x n counter-based hash matrix that the device fills through
+ * cgx_probe_fill_matrix_hash (csrc/cgx_kernels.h hash_entry), row-major, ld = n -- dense, incompressible test data for K1.
+ * Bit-identical to the device fill.  Uses the threads of oracle_set_threads. */
+void oracle_hash_rows(int n, long row0, long nrows, unsigned long long seed, int symmetric, double diag, double *A);
+
 /* One timed pass of the GEMV over a row block: used by bench.py's cpu_baseline leg. */
 double oracle_time_gemv_rows(int n, int nrows, int reps);
 

@@ -72,6 +72,8 @@ def lib():
         L.oracle_read_mtx_dense.restype = C.c_int
         L.oracle_set_threads.argtypes = [C.c_int]
         L.oracle_set_threads.restype = None
+        L.oracle_hash_rows.argtypes = [C.c_int, C.c_long, C.c_long, C.c_ulonglong, C.c_int, C.c_double, dp]
+        L.oracle_hash_rows.restype = None
         L.oracle_time_gemv_rows.argtypes = [C.c_int, C.c_int, C.c_int]
         L.oracle_time_gemv_rows.restype = C.c_double
         _lib = L
@@ -93,6 +95,39 @@ def generate_lap2d(n, row0=0, nrows=None):
     nrows = n if nrows is None else nrows
     A = np.empty((nrows, n), dtype=np.float64)
     lib().oracle_generate_lap2d_rows(n, row0, nrows, _dp(A))
+    return A
+
+
+def hash_rows(n, row0, nrows, seed, symmetric=False, diag=0.0):
+    """Rows [row0, row0+nrows) of the n x n counter-based hash matrix (oracle_hash_rows): what cgx_probe_fill_matrix_hash leaves
+    in HBM, rebuilt on the host.  Not a reference function: dense, incompressible test data for the GEMV of cg.cc:101-102."""
+    A = np.empty((nrows, n), dtype=np.float64)
+    lib().oracle_hash_rows(n, int(row0), int(nrows), int(seed), 1 if symmetric else 0, float(diag), _dp(A))
+    return A
+
+
+def hash_rows_numpy(n, rows, seed, symmetric=False, diag=0.0):
+    """The same definition written a second time, in numpy integer arithmetic (rows: any list of row indices): the
+    cross-check of the C loop above, and of the device fill at small sizes."""
+    M = (1 << 64) - 1
+
+    def mix(z):   # splitmix64 finaliser on uint64 arrays (wrapping arithmetic)
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return z ^ (z >> np.uint64(31))
+
+    with np.errstate(over="ignore"):
+        sm = mix(np.array([int(seed) & M], dtype=np.uint64))[0]
+        i = np.asarray(rows, dtype=np.uint64)[:, None]
+        j = np.arange(n, dtype=np.uint64)[None, :]
+        a, b = (np.minimum(i, j), np.maximum(i, j)) if symmetric else (np.broadcast_to(i, (i.shape[0], n)), np.broadcast_to(j, (i.shape[0], n)))
+        h = mix(sm ^ ((a << np.uint64(32)) | b))
+    A = (h >> np.uint64(11)).astype(np.float64) * 2.0 ** -52 - 1.0
+    if diag != 0.0:
+        for k, r in enumerate(np.asarray(rows, dtype=np.int64)):
+            if r < n:
+                A[k, r] = diag
     return A
 
 

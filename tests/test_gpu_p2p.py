@@ -66,6 +66,33 @@ def test_p2p_more_chunk_pairs_than_threads(tmp_path, tagged, port):
     _check_p2p(v, 200000)
 
 
+@pytest.mark.parametrize("world,n,iters,port", [(2, 3000, 12, 29751), (3, 1500, 12, 29752)])
+def test_p2p_epoch_boundaries(tmp_path, world, n, iters, port):
+    """The 64-bit epoch counter of the exchange moved (test hook) to just below 2^19, 0xFFF80000, 2^32 - 1, 2^32 and
+    2 (2^32 - 1): a solve across each boundary, after a previous solve left its plain-double all-gathers in the mailbox, gives
+    the bits of the first solve -- in both forms of the fused exchange, on every rank (real processes on one GPU)."""
+    out = tmp_path / "epochs.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "p2p_epoch_worker.py"),
+           str(n), str(iters), str(out)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420,
+                       env=dict(os.environ, OMP_NUM_THREADS="1", MASTER_ADDR="127.0.0.1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    v = json.load(open(out))
+    assert v["ranks_agree"], v
+    base = v["forms"]["flag"]["runs"][0]["digest"]
+    for form in ("flag", "tagged"):
+        f = v["forms"][form]
+        assert f["selftest_ok"] and f["backwards_refused"], v
+        assert len(f["runs"]) == 6
+        for q in f["runs"]:
+            assert q["digest"] == base and q["k"] == iters, (form, q, base)
+        # tagged words: the fused exchange alone counts on channel 1 (the plain all-gathers of begin / end have channel 0);
+        # flag words: begin's and end's all-gather of segments count there as well
+        for q in f["runs"][1:]:
+            assert q["end"] == q["start"] + iters + (0 if form == "tagged" else 2), (form, q)
+
+
 def _check_p2p(v, n):
     assert v["selftest_ok"], v
     assert v["ranks_agree"], v

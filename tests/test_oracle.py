@@ -293,3 +293,66 @@ def test_oracle_solves_do_not_depend_on_the_callers_floating_point_environment(o
     assert np.array_equal(x, x_ref) and r["residual_prev"] == r_ref["residual_prev"] and r["x_norm"] == r_ref["x_norm"]
     xb_ref, rb_ref = oracle.solve_lap2d_banded(n, it, 0.0, p)
     assert np.array_equal(xb, xb_ref) and rb["residual_prev"] == rb_ref["residual_prev"]
+
+
+# ---- the hash matrix of the dense-data probes (test data, not a reference function) ------------------------------------
+HASH_KNOWN = [   # (seed, i, j) -> value, from an independent big-integer evaluation of the definition (tests/golden: none needed)
+    ((0, 0, 0), "0x1.3836e97a68cbcp-2"),
+    ((1, 0, 1), "0x1.a7f58127596bcp-1"),
+    ((0x5EEDC0DE, 16376, 32767), "0x1.ae8f8e8b1527cp-2"),
+    ((0x5EEDC0DE, 46339, 0), "0x1.20f991012f210p-2"),
+    ((2 ** 63 + 5, 131071, 131070), "0x1.90d517aa00f98p-1"),
+]
+
+
+def _hash_entry_bigint(seed, i, j, sym=False, diag=0.0):
+    """cgx_kernels.h hash_entry once more, in Python integers: mix64 = the splitmix64 finaliser."""
+    M = (1 << 64) - 1
+
+    def mix(z):
+        z = (z + 0x9E3779B97F4A7C15) & M
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M
+        return z ^ (z >> 31)
+
+    if i == j and diag != 0.0:
+        return diag
+    a, b = (min(i, j), max(i, j)) if sym else (i, j)
+    return (mix(mix(seed) ^ ((a << 32) | b)) >> 11) * 2.0 ** -52 - 1.0
+
+
+def test_hash_matrix_known_answers(oracle):
+    for (seed, i, j), want in HASH_KNOWN:
+        assert _hash_entry_bigint(seed, i, j) == float.fromhex(want)
+        assert oracle.hash_rows(max(i, j) + 1, i, 1, seed, False, 0.0)[0, j] == float.fromhex(want)
+        assert oracle.hash_rows_numpy(max(i, j) + 1, [i], seed, False, 0.0)[0, j] == float.fromhex(want)
+
+
+@pytest.mark.parametrize("sym,diag", [(False, 0.0), (True, 0.0), (True, 215.5), (False, -3.0)])
+def test_hash_matrix_restatements_agree(oracle, sym, diag):
+    n, seed = 411, 0xABCDEF
+    A = oracle.hash_rows(n, 0, n, seed, sym, diag)
+    assert np.array_equal(A, oracle.hash_rows_numpy(n, range(n), seed, sym, diag))
+    assert np.array_equal(A[37:40], oracle.hash_rows(n, 37, 3, seed, sym, diag))
+    rng = np.random.default_rng(3)
+    for i, j in rng.integers(0, n, size=(50, 2)):
+        assert A[i, j] == _hash_entry_bigint(seed, int(i), int(j), sym, diag)
+    assert A.min() >= -1.0 and A.max() < 1.0 or diag != 0.0
+    if sym:
+        assert np.array_equal(A, A.T)
+    oracle.set_threads(4)
+    try:
+        assert np.array_equal(A, oracle.hash_rows(n, 0, n, seed, sym, diag))   # thread count does not change the fill
+    finally:
+        oracle.set_threads(1)
+
+
+def test_hash_matrix_with_dominant_diagonal_is_spd(oracle):
+    """What the rate runs and the fused-K1 test rely on: symmetric + diag just above 2 sqrt(n/3) is positive definite."""
+    n = 1500
+    diag = 1.03 * 2.0 * np.sqrt(n / 3.0)
+    A = oracle.hash_rows(n, 0, n, 99, True, diag)
+    w = np.linalg.eigvalsh(A)
+    assert w[0] > 0.0 and w[-1] / w[0] < 400.0
+    x, r = oracle.solve(A, oracle.init_source_term(n), max_iter=n, tol=1e-10)
+    assert r["converged"] and r["rel_residual"] < 1e-11

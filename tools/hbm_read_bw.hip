@@ -1,5 +1,7 @@
 // Dev tool: ceiling of a pure streaming READ on this MI355X (what K1 can reach at most).
-// hipcc --offload-arch=gfx950 -O3 tools/hbm_read_bw.hip -o /tmp/hbm_read_bw && /tmp/hbm_read_bw
+// hipcc --offload-arch=gfx950 -O3 tools/hbm_read_bw.hip -o /tmp/hbm_read_bw && /tmp/hbm_read_bw [MiB] [const|hash]
+// const: every byte 0x11 (rounds 1-3); hash: every double a different number in [-1, 1) with a random mantissa (the
+// splitmix64 finaliser of the element index: the data of cgx_probe_fill_matrix_hash) -- is the ceiling data dependent?
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -23,12 +25,26 @@ __global__ __launch_bounds__(256) void k_read(const double* __restrict__ a, size
     }
     if (s0 + s1 == 12345.678) out[blockIdx.x] = s0;   // keep the loads alive
 }
+__global__ __launch_bounds__(256) void k_fill_hash(double* a, size_t n)
+{
+    for (size_t t = (size_t)blockIdx.x * 256 + threadIdx.x; t < n; t += (size_t)gridDim.x * 256) {
+        unsigned long long z = t + 0x9E3779B97F4A7C15ull;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        a[t] = (double)(z >> 11) * 0x1.0p-52 - 1.0;
+    }
+}
 int main(int argc, char** argv)
 {
     const size_t bytes = (argc > 1 ? (size_t)atol(argv[1]) : 8192ull) << 20;   // MiB
     double *a, *out;
     hipMalloc(&a, bytes); hipMalloc(&out, 1 << 20);
-    hipMemset(a, 0x11, bytes);
+    const bool hash = argc > 2 && argv[2][0] == 'h';
+    if (hash) hipLaunchKernelGGL(k_fill_hash, dim3(8192), dim3(256), 0, 0, a, bytes / 8);
+    else hipMemset(a, 0x11, bytes);
+    hipDeviceSynchronize();
+    printf("fill: %s\n", hash ? "hash (incompressible doubles in [-1,1))" : "const 0x11");
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     struct Cfg { int wgs; int u; bool nt; };
     std::vector<Cfg> cfgs = {{4096, 8, true}, {4096, 16, true}, {2048, 16, true}, {8192, 8, true}, {1024, 16, true}, {512, 16, true}, {4096, 16, false}, {16384, 8, true}};
