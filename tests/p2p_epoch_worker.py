@@ -5,7 +5,7 @@ below a boundary, so that the solve runs ACROSS it -- after the previous solve l
 (plain doubles: x, the initial Ap) wherever the mailbox layout puts them:
   2^19, 0xFFF80000       round 3's tag = epoch ^ 0xFFF80000 stopped being a NaN pattern / became 0 there
   2^32 - 1, 2 (2^32 - 1) the 32-bit tag of the tagged form wraps (tag = 1 + epoch mod (2^32 - 1))
-  2^32                   the epoch's low 32 bits wrap
+  2^32                   the epoch's low 32 bits wrap (crossed by the same solve as 2^32 - 1)
 Every solve must give the bits of the first one, on every rank, in both forms.  argv: n iters out.json"""
 import hashlib
 import json
@@ -21,7 +21,7 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as g  # noqa: E402
 
 M = 2 ** 32 - 1
-BOUNDARIES = [2 ** 19, 0xFFF80000, M, 2 ** 32, 2 * M]
+BOUNDARIES = [2 ** 19, 0xFFF80000, M, 2 * M]   # the solve across M = 2^32 - 1 also crosses 2^32
 
 
 def main():
