@@ -83,6 +83,12 @@ def parse_args():
                     help="seconds one transport's wire-up stage may take before that transport is dropped")
     ap.add_argument("--watchdog", type=float, default=float(os.environ.get("CGX_BENCH_WATCHDOG", "480")),
                     help="seconds after which rank 0 prints a failure line and the process exits")
+    ap.add_argument("--no-dense-check", action="store_true",
+                    help="skip the dense-data leg (after the timed region: the same K1 on a matrix in which every element is a "
+                         "different number -- roofline.dense_random; ~K more iterations)")
+    # tests only (tests/test_gpu_bench.py): "<transport>:<stage>" or "extra:cpu baseline" never comes back.  An explicit
+    # argument, not an environment variable: nothing in a user's environment changes what the benchmark does.
+    ap.add_argument("--test-hang", default="", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -126,10 +132,21 @@ def live_pmc_traffic(args, n):
             env = {k: v for k, v in os.environ.items()           # the child is a plain one-GPU run, never a rank of somebody's job
                    if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR",
                                 "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(env, TMPDIR="/tmp"), capture_output=True, text=True, timeout=100)
+            # its own process group, known to stop_launched(): on a timeout, the watchdog or SIGTERM the profiler AND the
+            # bench.py under it (which holds an 8 GiB matrix on the GPU this process still uses) are ended together
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=dict(env, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                                    text=True, start_new_session=True)
+            LAUNCHED["extra"] = proc
+            try:
+                _, err = proc.communicate(timeout=100)
+            except subprocess.TimeoutExpired:
+                stop_group(proc)
+                return None, "rocprofv3 --pmc %s pass did not finish within 100 s (its process group was ended)" % counter
+            finally:
+                LAUNCHED["extra"] = None
             files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
-            if r.returncode != 0 or not files:
-                return None, "rocprofv3 --pmc %s pass failed (rc %d): %s" % (counter, r.returncode, r.stderr[-300:])
+            if proc.returncode != 0 or not files:
+                return None, "rocprofv3 --pmc %s pass failed (rc %d): %s" % (counter, proc.returncode, (err or "")[-300:])
             vals = [float(row["Counter_Value"]) for row in csv.DictReader(open(files[0]))
                     if row["Counter_Name"] == counter and K1_FUSED.search(row["Kernel_Name"])]
             if not vals:
@@ -359,7 +376,7 @@ class Bench:
 
         def stage(what, fn, bounded=True):
             ok = True
-            if bounded and os.environ.get("CGX_BENCH_TEST_HANG") == "%s:%s" % (transport, what):
+            if bounded and args.test_hang == "%s:%s" % (transport, what):
                 inner = fn                            # test hook (tests/test_gpu_bench.py): this stage never comes back
 
                 def fn():                             # noqa: F811
@@ -532,6 +549,23 @@ class Bench:
                 "what": "one cgx_solve() of K iterations, the reference's window cg_main.cc:53-55 (setup + initial "
                         "GEMV + loop + gather of x + verification GEMV), max over ranks"}
 
+    def dense_leg(self, s, warmup, steps):
+        """K1 of the same solver on dense incompressible data: [median ms, samples, finite] of every rank, or None."""
+        ok = True
+        try:
+            s.probe_fill_matrix_hash(0x5EEDC0DE, symmetric=True, diag=1.03 * 2.0 * math.sqrt(self.n / 3.0))
+            s.init_source_term(1.0 / self.n)
+        except Exception as e:             # noqa: BLE001
+            self.log("dense-data leg: fill failed: %s" % e)
+            ok = False
+        if not self.all_ok(ok):
+            return None
+        out = self.run(s, warmup, steps)
+        if out is None:
+            return None
+        _, r, _ = out
+        return self.gather_rows([r["gemv_ms_median"], float(r["gemv_launches"]), 1.0 if math.isfinite(r["residual_prev"]) else 0.0])
+
     def measure(self):
         args, world, rank, n, pkg = self.args, self.world, self.rank, self.n, self.pkg
         if not self.use_comm:
@@ -573,7 +607,13 @@ class Bench:
                     calib[tname] = self.max_over_ranks(c[0]) / 60 * 1e3
         self.state["stage"] = "timed run"
         out, transport, solver = None, None, None
-        for tname in sorted(solvers, key=lambda t: calib.get(t, 0.0)):
+        # auto: the tagged-word form is built, self-tested and calibrated for the record, but it does not carry the timed run
+        # unless it is asked for by name (--transport p2p-tag): it rests on an 8-byte half of a 16-byte write-through store
+        # arriving untorn over xGMI, which no run on more than one GPU has shown yet.
+        eligible = [t for t in solvers if not (args.transport == "auto" and t == "p2p-tag" and len(solvers) > 1)]
+        if "p2p-tag" in solvers and "p2p-tag" not in eligible:
+            self.notes.append("p2p-tag calibrated for the record only (auto never selects it; --transport p2p-tag runs it)")
+        for tname in sorted(eligible, key=lambda t: calib.get(t, 0.0)):
             out = self.run(solvers[tname], args.warmup, args.steps)
             if out is not None:
                 transport, solver = tname, solvers[tname]
@@ -605,6 +645,15 @@ class Bench:
 
         self.state["stage"] = "solve-window run"
         window = None if args.no_solve_window else self.solve_window(solver, args.steps)
+
+        # Dense-data leg (last thing done with the solver: it overwrites the matrix).  generate_lap2d_matrix leaves 5 non-zeros
+        # per row (cg.cc:178-186), the reference's GEMV is a general dense dgemv (cg.cc:101-102): the same K1 launches once more
+        # on a row block in which every element is a different number (cgx_probe_fill_matrix_hash: symmetric, dominant
+        # diagonal, so CG keeps running), same steps, same event timing.
+        dense = None
+        if not args.no_dense_check and self.profile_every:
+            self.state["stage"] = "dense-data leg"
+            dense = self.dense_leg(solver, args.warmup, args.steps)
 
         if rank != 0:
             return None
@@ -644,6 +693,21 @@ class Bench:
             else:
                 roof["note"] = ("median_launch_ms exceeds ms_per_step: the K1 timing is not trustworthy for this run, "
                                 "no fraction is reported")
+        if dense is not None and lim is not None:
+            dmed, dcnt, dfin = dense[lim["rank"]]
+            if dmed > 0 and dfin:
+                ratio = dmed / lim["median_ms"]
+                roof["dense_random"] = {
+                    "what": "the same K1 (same rank, same steps, same event timing) on a row block in which every element is a "
+                            "different number in [-1, 1) (cgx_probe_fill_matrix_hash: counter-based hash, symmetric, dominant diagonal) "
+                            "instead of generate_lap2d_matrix's 5 non-zeros per row; run after the timed region",
+                    "median_launch_ms": dmed, "launches_timed": int(dcnt),
+                    "achieved": lim["bytes_per_launch"] / (dmed * 1e-3) / 1e9, "frac": lim["bytes_per_launch"] / (dmed * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "time_ratio_to_generated_matrix": ratio,
+                }
+                if abs(ratio - 1.0) > 0.01:
+                    roof["dense_random"]["note"] = ("K1 on dense data differs from K1 on the generated matrix by more than 1 % on this box: "
+                                                    "the headline fraction is data dependent here")
         line = base_line(args, world, n)
         rows0 = counts[0]
         line.update({"value": args.steps / elapsed, "ms_per_step": ms_per_step})
@@ -722,7 +786,7 @@ class Bench:
         if not args.no_cpu_baseline:
             # rank 0 only, after the timed region and outside every bracket; the other ranks wait at the teardown barrier
             self.state["stage"] = "cpu baseline"
-            if os.environ.get("CGX_BENCH_TEST_HANG") == "extra:cpu baseline":   # test hook: an extra that never comes back
+            if args.test_hang == "extra:cpu baseline":   # test hook: an extra that never comes back
                 time.sleep(3600)
             line["cpu_baseline"] = cpu_baseline(n, args.cpu_baseline_iters)
         return line
@@ -741,12 +805,13 @@ def free_port():
         return sk.getsockname()[1]
 
 
-LAUNCHED = {"proc": None}      # the launcher child of self_launch, for the watchdog / SIGTERM paths to stop
+# children with a process group of their own, for the watchdog / SIGTERM paths to stop: the launcher child of self_launch
+# ("proc") and the rocprofv3 pass of live_pmc_traffic that is running right now ("extra")
+LAUNCHED = {"proc": None, "extra": None}
 
 
-def stop_launched():
-    """End the launcher child and every rank under it (its own process group), if there is one."""
-    proc = LAUNCHED["proc"]
+def stop_group(proc):
+    """End a child that was started with start_new_session=True, and everything under it."""
     if proc is None or proc.poll() is not None:
         return
     for sig, wait in ((signal.SIGTERM, 10.0), (signal.SIGKILL, 5.0)):
@@ -759,6 +824,12 @@ def stop_launched():
             return
         except subprocess.TimeoutExpired:
             pass
+
+
+def stop_launched():
+    """End the launcher child and every rank under it, and a counter pass in flight, if there is one."""
+    stop_group(LAUNCHED["proc"])
+    stop_group(LAUNCHED["extra"])
 
 
 def self_launch(args, emit_raw, failure_line, state):

@@ -51,6 +51,11 @@ def test_bench_line_contract(gpu_pkg):
         # a box that cannot start the profiler (no rocprofv3, no counter access): the line says why and falls back
         assert rf["traffic_live_note"] and rf["traffic"] is None
     assert rf["traffic_committed"] is None          # no committed row for N = 4096
+    # the dense-data leg: the same K1 on a matrix in which every element is a different number, same window
+    dr = rf["dense_random"]
+    assert dr["launches_timed"] == rf["launches_timed"] and dr["median_launch_ms"] > 0
+    assert abs(dr["time_ratio_to_generated_matrix"] - dr["median_launch_ms"] / rf["median_launch_ms"]) < 1e-12
+    assert abs(dr["frac"] - rf["bytes_per_launch"] / (dr["median_launch_ms"] * 1e-3) / 1e9 / 8000.0) < 1e-12
 
 
 def test_bench_short_window_statistics(gpu_pkg, oracle):
@@ -107,7 +112,7 @@ def test_bench_two_ranks_over_the_mailboxes(gpu_pkg, oracle):
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
     d = one_line(r.stdout)
     c = d["config"]
-    assert d["n_gpus"] == 2 and c["transport"] in ("p2p-tag", "p2p", "p2p-sep") and c["ranks_seen"] == 2
+    assert d["n_gpus"] == 2 and c["transport"] in ("p2p", "p2p-sep") and c["ranks_seen"] == 2
     assert set(c["transport_calibration_ms_per_iteration"]) == {"p2p-tag", "p2p", "p2p-sep"}
     assert c["transport_ranks_wired"] == [2, 2] and c["distinct_gpus"] == 1 and c["process_group_ranks"] == 2
     assert any("rccl" in note for note in c["transport_notes"])
@@ -150,8 +155,12 @@ def test_bench_auto_transport_one_rank_under_the_launcher(gpu_pkg):
     d = one_line(r.stdout)
     c = d["config"]
     assert set(c["transport_calibration_ms_per_iteration"]) == {"p2p-tag", "p2p", "p2p-sep", "rccl"}
-    assert c["transport"] in ("p2p-tag", "p2p", "p2p-sep", "rccl") and c["transport_notes"] is None
-    assert c["transport"] == min(c["transport_calibration_ms_per_iteration"], key=c["transport_calibration_ms_per_iteration"].get)
+    # the tagged-word form is calibrated for the record but auto never lets it carry the timed run (no multi-GPU run has shown
+    # its 16-byte stores untorn over xGMI yet): the fastest of the others does
+    assert c["transport"] in ("p2p", "p2p-sep", "rccl")
+    assert c["transport_notes"] == ["p2p-tag calibrated for the record only (auto never selects it; --transport p2p-tag runs it)"]
+    others = {t: v for t, v in c["transport_calibration_ms_per_iteration"].items() if t != "p2p-tag"}
+    assert c["transport"] == min(others, key=others.get)
     assert c["rccl_nranks"] == 1          # from the RCCL candidate of the calibration, whichever transport carried the run
     assert d["value"] > 0 and d["roofline"]["consistency"] == "ok" and d["roofline"]["launches_timed"] == 19
 
@@ -179,11 +188,11 @@ def test_bench_four_ranks_uneven_partition(gpu_pkg, oracle):
 def test_bench_survives_a_wireup_stage_that_never_returns(gpu_pkg):
     """A hung ncclCommInitRank (simulated: the stage sleeps for an hour) is abandoned after --wireup-timeout, RCCL is
     dropped with a note, the mailbox transports carry the run, and the process still ends (os._exit past the stuck thread)."""
-    r = torchrun(1, 29726, ["--steps", "20", "--warmup", "5", "--matrix-size", "4096", "--no-cpu-baseline", "--wireup-timeout", "3"],
-                 env={"CGX_BENCH_TEST_HANG": "rccl:ncclCommInitRank"}, timeout=300)
+    r = torchrun(1, 29726, ["--steps", "20", "--warmup", "5", "--matrix-size", "4096", "--no-cpu-baseline", "--wireup-timeout", "3", "--test-hang", "rccl:ncclCommInitRank"],
+                 timeout=300)
     d = one_line(r.stdout)
     c = d["config"]
-    assert d["value"] > 0 and c["transport"] in ("p2p-tag", "p2p", "p2p-sep")
+    assert d["value"] > 0 and c["transport"] in ("p2p", "p2p-sep")
     assert set(c["transport_calibration_ms_per_iteration"]) == {"p2p-tag", "p2p", "p2p-sep"}
     assert any("rccl" in note and "did not finish within 3 s" in note for note in c["transport_notes"])
     assert r.returncode == 0, r.stderr[-2000:]
@@ -272,8 +281,8 @@ def test_bench_self_launch_weak_mode_two_ranks(gpu_pkg, oracle):
 def test_bench_keeps_the_measurement_when_an_extra_hangs(gpu_pkg):
     """The CPU baseline (or a live counter pass) never comes back: the watchdog prints the line that was complete before it --
     value, roofline, everything measured -- with a note, and the exit code stays 0."""
-    r = subprocess.run([sys.executable, BENCH, "--steps", "20", "--warmup", "5", "--matrix-size", "4096", "--no-live-pmc", "--watchdog", "18"],
-                       capture_output=True, text=True, timeout=300, env=dict(os.environ, CGX_BENCH_TEST_HANG="extra:cpu baseline"))
+    r = subprocess.run([sys.executable, BENCH, "--steps", "20", "--warmup", "5", "--matrix-size", "4096", "--no-live-pmc", "--watchdog", "18",
+                        "--test-hang", "extra:cpu baseline"], capture_output=True, text=True, timeout=300)
     d = one_line(r.stdout)
     assert r.returncode == 0, r.stderr[-2000:]
     assert d["value"] > 0 and d["roofline"]["consistency"] == "ok" and "cpu_baseline" not in d and "error" not in d

@@ -108,8 +108,8 @@ def _check_p2p(v, n):
 @pytest.mark.parametrize("transport", ["p2p", "p2p-tag", "auto"])
 def test_cgsolver_cli_forked_ranks_over_mailboxes(tmp_path, transport):
     """`cgsolver N OUT MAXITER --gpus 3`: the CLI forks one process per rank before touching the GPU and wires
-    the mailboxes over pipes.  --same-device puts every rank on device 0 (one-GPU rehearsal).  auto = the tagged-word form
-    if its self-test passes on every rank, else the flag form, else RCCL."""
+    the mailboxes over pipes.  --same-device puts every rank on device 0 (one-GPU rehearsal).  auto = the flag form if its
+    self-test passes on every rank, else RCCL; the tagged-word form runs on request (--transport p2p-tag)."""
     exe = os.path.join(ROOT, "conjugate-gradient_amd", "cgsolver")
     out = tmp_path / "strong.txt"
     r = subprocess.run([exe, "2048", str(out), "200", "--gpus", "3", "--same-device", "--transport", transport, "--stats"],

@@ -105,3 +105,35 @@ def test_mtx_file():
     assert list(res) == [16]                             # BLOCK_WIDTH echoed
     assert [r[0] for r in res[16]] == [32, 256, 1024]    # NUM_THREADS echoed
     assert all(0 < r[1] < 0.822428 for r in res[16])     # the reference's best published CUDA time (results/CUDA_T.txt:48)
+
+
+def test_plot_script_reads_every_committed_file_without_an_edit(tmp_path):
+    """results/plot_mi355x.py restates the notebook's two MPI loaders with ITEMS taken from the file: it
+    must give the same numbers as the loaders above on every committed file, for one row per series (a one-GPU box) and
+    for a synthetic 4-row node file, and draw both figures."""
+    import importlib.util
+    import subprocess
+    import sys
+    spec = importlib.util.spec_from_file_location("plot_mi355x", os.path.join(RES, "plot_mi355x.py"))
+    pm = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pm)
+    assert list(pm.ALPHAS) == ALPHA_KEYS
+    for name in ("strong_scaling.txt", "strong_scaling_n32768.txt"):
+        mine, ref = pm.strong_series(os.path.join(RES, name)), load_strong(os.path.join(RES, name))
+        assert list(mine) == list(ref)
+        for n in ref:
+            assert [(p, t) for p, t, _, _ in mine[n]] == [tuple(r) for r in ref[n]]
+            assert [s for _, _, s, _ in mine[n]] == list(ref[n][0][1] / np.array([r[1] for r in ref[n]]))      # plots.ipynb:34
+    for name, n0s in (("weak_scaling.txt", [1024, 1448, 2048]), ("weak_scaling_n16384.txt", [16384])):
+        ss = pm.weak_series(os.path.join(RES, name))
+        assert [s[0][0] for s in ss] == n0s and all(s[0][3] == 1.0 for s in ss)
+    # a node file: three series of four rows (what experiments/cg_mi355x.run leaves on an 8-GPU node)
+    node = tmp_path / "weak_scaling.txt"
+    node.write_text("".join("%d,%d,%g\n" % (int(math.floor(n0 * math.sqrt(p))), p, 0.01 * (1 + 0.1 * k))
+                            for n0 in (1024, 1448, 2048) for k, p in enumerate((1, 2, 4, 8))))
+    ss = pm.weak_series(str(node))
+    assert [len(s) for s in ss] == [4, 4, 4] and [round(q[3], 6) for q in ss[2]] == [1.0, round(1 / 1.1, 6), round(1 / 1.2, 6), round(1 / 1.3, 6)]
+    r = subprocess.run([sys.executable, os.path.join(RES, "plot_mi355x.py"), "--png", str(tmp_path / "fig")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert "ITEMS = [1]" in r.stdout and "N=32768" in r.stdout
+    assert (tmp_path / "fig_strong.png").stat().st_size > 1000 and (tmp_path / "fig_weak.png").stat().st_size > 1000

@@ -60,6 +60,26 @@ while time.time() - t0 < budget:
             ro3["residual_prev"], ro["residual_prev"], np.linalg.norm(xo3 - xo), O.fp_state(), cases), flush=True)
         print("MISMATCH n=%d P=%d banded=%d variant=%d iters=%d every=%d err=%.3e res %r vs %r" %
               (n, P, banded, variant, iters, every, err, r["residual_prev"], ro["residual_prev"]), flush=True)
+        # Everything needed to analyse the case offline goes to a file: the inputs (the matrix by its rule: generate_lap2d(n)),
+        # what the GPU returned, what the oracle returned the first and the second time, the scalars of all three and the
+        # oracle's floating-point state.  (Round 3's one disagreement, profiles/r03_fuzz_long.txt, could only be replayed, and
+        # the replay passed: the oracle's first answer was gone.)
+        out_dir = os.environ.get("FUZZ_DUMP_DIR", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"))
+        os.makedirs(out_dir, exist_ok=True)
+        path = os.path.join(out_dir, "fuzz_mismatch_seed%s_case%d_n%d_P%d.npz" % (sys.argv[2] if len(sys.argv) > 2 else "0", cases, n, P))
+        with pkg.CGSolver(comm_mode=pkg.COMM_LOOPBACK if P > 1 else pkg.COMM_SELF, nranks=P, gemv_variant=variant,
+                          check_every=every, matrix_format=pkg.MATRIX_BANDED if banded else pkg.MATRIX_DENSE) as s:
+            s.generate_lap2d_matrix(n); s.set_source_term(b); s.set_max_iter(iters); s.tolerance(0.0)
+            x_again = x0.copy(); r_again = s.solve(x_again)
+        np.savez(path, matrix_rule="generate_lap2d(%d)" % n, n=n, P=P, banded=banded, variant=variant, iters=iters, check_every=every,
+                 b=b, x0=x0, x_gpu=x, x_gpu_again=x_again, x_oracle_first=xo, x_oracle_again=xo3,
+                 scalars_gpu=np.array([r["residual_prev"], r["x_norm"], r["rel_residual"]]),
+                 scalars_gpu_again=np.array([r_again["residual_prev"], r_again["x_norm"], r_again["rel_residual"]]),
+                 scalars_oracle_first=np.array([ro["residual_prev"], ro["x_norm"], ro["rel_residual"]]),
+                 scalars_oracle_again=np.array([ro3["residual_prev"], ro3["x_norm"], ro3["rel_residual"]]),
+                 mxcsr=O.fp_state(), gpu_bit_identical_again=np.array_equal(x, x_again), oracle_bit_identical_again=np.array_equal(xo, xo3))
+        print("case dumped to %s (GPU again bit-identical: %s, oracle again bit-identical: %s)" % (
+            path, np.array_equal(x, x_again), np.array_equal(xo, xo3)), flush=True)
         sys.exit(1)
     if cases % 200 == 0:
         print("%d cases ok, worst ||dx||/||x|| = %.2e, %.0f s" % (cases, worst, time.time() - t0), flush=True)

@@ -43,7 +43,7 @@ done
 g++ -fsanitize=address,undefined -g -O1 -std=c++17 -pthread -I$R/include -o cgsolver_asan $P/host/cg.cc $P/host/cg_main.cc -L$P -lcgx -Wl,-rpath,$P -Wl,-rpath,/opt/rocm/lib
 export HIP_VISIBLE_DEVICES=-1 ROCR_VISIBLE_DEVICES=-1 ASAN_OPTIONS=detect_leaks=0
 ( ./cgsolver_asan; ./cgsolver_asan 64 o.txt --cpu; ./cgsolver_asan 64 o.txt; ./cgsolver_asan 64 o.txt 5 --gpus 2;
-  CG_TEST_HANG_STAGE="device probe:1" ./cgsolver_asan 64 o.txt 5 --gpus 2 --wireup-timeout 1 ) > out_cli.txt 2>&1 || true
+  ./cgsolver_asan 64 o.txt 5 --gpus 2 --wireup-timeout 1 --test-hang-stage "device probe:1" ) > out_cli.txt 2>&1 || true
 if grep -E "ERROR: AddressSanitizer|runtime error:" out_cli.txt; then fail=1; fi
 echo "cgsolver (ASan + UBSan), five no-GPU invocations: $(grep -cE 'ERROR: AddressSanitizer|runtime error:' out_cli.txt) sanitizer reports"
 rm -rf $W
