@@ -14,5 +14,8 @@ if mode == "p2p":
 else:
     s = pkg.CGSolver(comm_mode=pkg.COMM_LOOPBACK if P > 1 else pkg.COMM_SELF, nranks=P, gemv_variant=v, profile_gemv=int(os.environ.get("PROFILE", "0")))
 s.generate_lap2d_matrix(n); s.set_max_iter(10**6); s.tolerance(0.0); s.init_source_term(1.0 / n)
-s.solve_begin(np.zeros(n)); s.solve_steps(300); s.solve_steps(100); r = s.solve_end()
-print(json.dumps({"n": n, "shards": P, "mode": mode, "variant": v, "plan": s.gemv_plan(0), "gemv_ms_avg": r["gemv_ms_avg"]}))
+import time
+s.solve_begin(np.zeros(n)); s.solve_steps(300); t0 = time.perf_counter(); s.solve_steps(100); t1 = time.perf_counter(); r = s.solve_end()
+print(json.dumps({"n": n, "shards": P, "mode": mode, "variant": v, "plan": s.gemv_plan(0), "gemv_ms_avg": r["gemv_ms_avg"],
+                  "combine": os.environ.get("CGX_K1_COMBINE", "0"), "wall_us_per_iteration_all_blocks": (t1 - t0) * 1e4,
+                  "residual_prev": r["residual_prev"]}))
