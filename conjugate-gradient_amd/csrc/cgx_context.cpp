@@ -57,7 +57,6 @@ void free_shard(Shard &s)
     (void)hipFree(s.partials);
     (void)hipFree(s.ap_parts);
     (void)hipFree(s.k1_scratch);
-    (void)hipFree(s.tickets);
     (void)hipFree(s.sc);
     (void)hipFree(s.gathered);
     s = Shard{};
@@ -249,14 +248,6 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
         if (s.plan.split > 1) {
             HIP_TRY(ctx, hipMalloc(&s.ap_parts, (size_t)s.plan.split * ctx->seg_Sr * sizeof(double)));
             HIP_TRY(ctx, hipMemsetAsync(s.ap_parts, 0, (size_t)s.plan.split * ctx->seg_Sr * sizeof(double), ctx->stream));
-        }
-        // Experiment (round 4, CGX_K1_COMBINE=1): the prefold folded into K1 by arrival tickets -- for the
-        // default multi-rank shape of every transport that would otherwise launch k_prefold_ap.
-        if (ctx->chunked && !fused_p2p && s.plan.split > 1 && s.plan.light && s.plan.R == 8 && s.plan.U == 2 && getenv("CGX_K1_COMBINE") &&
-            atoi(getenv("CGX_K1_COMBINE")) != 0) {
-            const size_t words = (size_t)(s.plan.grid / s.plan.split + cpr + 8);
-            HIP_TRY(ctx, hipMalloc(&s.tickets, words * sizeof(unsigned)));
-            HIP_TRY(ctx, hipMemsetAsync(s.tickets, 0, words * sizeof(unsigned), ctx->stream));
         }
         if (ctx->chunked) {
             HIP_TRY(ctx, hipMalloc(&s.k1_scratch, (size_t)(grid_max + 8) * sizeof(double)));

@@ -31,7 +31,6 @@ struct Shard {
     double *ap_parts = nullptr;  // plan.split > 1: split x seg_Sr doubles, the column pieces of the fused K1's Ap
     double *k1_scratch = nullptr;   // chunked exchange: where K1's per-workgroup p.Ap partials go (only the gemv probe reads them;
                                     // the segment tail then holds one partial per chunk of the slice instead)
-    unsigned *tickets = nullptr; // experiment (CGX_K1_COMBINE=1): arrival words of the K1 that folds the prefold into itself
     double *partials = nullptr;  // scratch: per-workgroup partial sums of K3 and of the setup kernels
     Scalars *sc = nullptr;
     double *gathered = nullptr;  // kMaxRanks * kSlots doubles (DEBUG scalars of all ranks)

@@ -80,11 +80,7 @@ hipError_t launch_gemv_plain(const GemvPlan &plan, const double *A, long lda, in
 hipError_t launch_gemv_fused(const GemvPlan &plan, const double *A, long lda, int rows, int row0,
                              const double *p_old, double *p_new, SegView seg, double *Ap, double *partials,
                              Scalars *sc, int k, double tol, hipStream_t s, hipEvent_t e_start = nullptr,
-                             hipEvent_t e_stop = nullptr, long ap_stride = 0,
-                             // experiment (CGX_K1_COMBINE): tickets != nullptr folds launch_prefold_ap into this launch by arrival
-                             // tickets (plan (8,2) light with split > 1, partials == nullptr): tickets = grid / split + chunks
-                             // zeroed words, seg_ap = the Ap slice of the segment, seg_tail = its chunk partials
-                             unsigned *tickets = nullptr, double *seg_ap = nullptr, double *seg_tail = nullptr);
+                             hipEvent_t e_stop = nullptr, long ap_stride = 0);
 // Chunks of a rank's Ap slice (see "Chunks" in cgx_kernels.hip): kChunkRows consecutive rows, one workgroup each.
 constexpr int kChunkRows = 512;
 inline int chunks_per_rank(int Sr) { return (Sr + kChunkRows - 1) / kChunkRows; }

@@ -129,7 +129,6 @@ __device__ __forceinline__ double block_sum(double v, double *lds /* >= WAVES do
 }
 
 enum { kPlain = 0, kFusedSingle = 1 };   // the fused form always reads the replicated, contiguous r
-constexpr int kMaxSplit = 8;             // column pieces per row group of K1 (one per XCD)
 
 template <bool NT>
 __device__ __forceinline__ d2 load_a(const double *ptr)
@@ -283,25 +282,13 @@ __device__ __forceinline__ d2 make_p(const SegView &sv, double beta, d2 p_old, i
 // PART = false (one-round form only): nobody consumes this launch's per-workgroup p.Ap partials (chunked exchange: the
 // consumer of Ap reduces one partial per 512-row chunk itself), so the epilogue's two operand loads, the product and the
 // store are left out.
-// COMBINE (experiment, round 4; CGX_K1_COMBINE=1; split > 1, PART = false): the work of k_prefold_ap done inside this launch
-// by arrival tickets.  The `split` column pieces of a row group store their partial row sums write-through, drain, and take a
-// ticket on the group's word; the piece that arrives last adds all pieces in ascending order (the order of chunk_pair) and
-// stores the R rows of the Ap slice write-through, then takes a ticket on the word of its 512-row chunk; the row group that
-// arrives last there reduces the chunk's p.Ap partial exactly as chunk_dot<4> does (four virtual waves of 64 row pairs each,
-// butterfly per wave, the four totals added in order), with p = r + beta p_old recomputed from this launch's inputs (another
-// workgroup of this launch stores p_new).  Same bits as the prefold kernel; one kernel and one boundary fewer per iteration.
-// Visibility across XCDs without fences, the guide's write-through form: every handed-off byte is stored sc1 (agent-scope
-// relaxed atomic store), the storing wave waits for vmcnt(0) before its ticket, and every load of such a byte is an sc1 load.
-// The last arriver leaves the word at 0 for the next launch.
-template <int R, int U, int WAVES, int MODE, bool LIGHT = false, bool PART = true, bool COMBINE = false>
+template <int R, int U, int WAVES, int MODE, bool LIGHT = false, bool PART = true>
 __global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 1))) void k_gemv_colsplit(const double *__restrict__ A, long lda, int ncols_all, int rows,
                                                                int row0_global, const double *__restrict__ v,
                                                                double *__restrict__ p_new, SegView sv,
                                                                double *__restrict__ Ap, double *partials,
-                                                               Scalars *sc, int k, double tol, int split, long ap_stride,
-                                                               unsigned *tickets, double *seg_ap, double *seg_tail)
+                                                               Scalars *sc, int k, double tol, int split, long ap_stride)
 {
-    static_assert(!COMBINE || (LIGHT && !PART && MODE != kPlain && (kChunkRows % R) == 0), "COMBINE: the fused one-round form without per-workgroup partials");
     constexpr bool FUSED = MODE != kPlain;
     constexpr bool NT = true;   // A is streamed once: non-temporal loads keep p and r in L2 (+12 % measured)
     __shared__ double red[WAVES][R];
@@ -479,9 +466,7 @@ __global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 
 #pragma unroll
             for (int i = 1; i < WAVES; ++i) s += red[i][lane];
             const long row = row0 + lane;
-            if constexpr (COMBINE) {
-                if (row < rows) __hip_atomic_store(Ap + row, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // write-through (sc1)
-            } else if (row < rows) {
+            if (row < rows) {
                 Ap[row] = s;
                 if constexpr (PART) {
                     const int j = row0_global + (int)row;
@@ -497,63 +482,6 @@ __global__ __launch_bounds__(WAVES * 64, (LIGHT ? 2 : ((R == 8 && U == 2) ? 4 : 
             // One partial per workgroup; K3 folds all of them (all ranks') in a fixed order.  No ticket here:
             // 4096 workgroups taking a returning atomic on one word cost 3-10 % of K1 (measured).
             if (lane == 0) partials[blockIdx.x] = d;
-        }
-        if constexpr (COMBINE) {
-            if (rows <= 0) return;                                      // a shard without rows (N < P): nothing to hand over
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // this piece's rows have been written through
-            unsigned t1 = 0;
-            if (lane == 0) t1 = __hip_atomic_fetch_add(tickets + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            t1 = (unsigned)__builtin_amdgcn_readfirstlane((int)t1);
-            if (t1 != (unsigned)split - 1u) return;                     // not the last piece of this row group
-            if (lane == 0) __hip_atomic_store(tickets + group, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // all pieces of my R rows, ascending (chunk_pair's order); clamped loads, every one in flight at once
-            const double *parts = Ap - (long)piece * ap_stride;
-            long row = row0 + (lane & (R - 1));
-            if (row > rows - 1) row = rows - 1;
-            double pv8[kMaxSplit];
-#pragma unroll
-            for (int sp = 0; sp < kMaxSplit; ++sp)
-                pv8[sp] = __hip_atomic_load(parts + (long)(sp < split ? sp : split - 1) * ap_stride + row, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            double a = pv8[0];
-#pragma unroll
-            for (int sp = 1; sp < kMaxSplit; ++sp) a = sp < split ? a + pv8[sp] : a;
-            if (lane < R && row0 + lane < rows) __hip_atomic_store(seg_ap + row0 + lane, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int c = (int)(row0 / kChunkRows);
-            const int c_rows = (rows - c * kChunkRows < kChunkRows) ? rows - c * kChunkRows : kChunkRows;
-            const unsigned c_groups = (unsigned)((c_rows + R - 1) / R);
-            unsigned t2 = 0;
-            if (lane == 0) t2 = __hip_atomic_fetch_add(tickets + groups + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            t2 = (unsigned)__builtin_amdgcn_readfirstlane((int)t2);
-            if (t2 != c_groups - 1u) return;                            // not the last row group of this chunk
-            if (lane == 0) __hip_atomic_store(tickets + groups + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // the chunk's p.Ap partial, bit for bit chunk_dot<4>(chunk_p, chunk_pair): virtual thread t = vw * 64 + lane owns
-            // the row pair (2t, 2t+1) of the chunk
-            double tot[4];
-            d2 aa[4], pp[4], rr2[4];
-#pragma unroll
-            for (int vw = 0; vw < 4; ++vw) {
-                const int lr = c * kChunkRows + 2 * (vw * 64 + lane);   // local row of the pair
-                const int l0 = lr < rows ? lr : rows - 1, l1 = lr + 1 < rows ? lr + 1 : rows - 1;
-                aa[vw].x = __hip_atomic_load(seg_ap + l0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                aa[vw].y = __hip_atomic_load(seg_ap + l1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                pp[vw].x = v[row0_global + l0];
-                pp[vw].y = v[row0_global + l1];
-                rr2[vw].x = rfull[row0_global + l0];
-                rr2[vw].y = rfull[row0_global + l1];
-            }
-#pragma unroll
-            for (int vw = 0; vw < 4; ++vw) {
-                const int lr = c * kChunkRows + 2 * (vw * 64 + lane);
-                const double ax = lr < rows ? aa[vw].x : 0.0, ay = lr + 1 < rows ? aa[vw].y : 0.0;
-                const double px = lr < rows ? fma(beta, pp[vw].x, rr2[vw].x) : 0.0;       // the bits of the stored p_new
-                const double py = lr + 1 < rows ? fma(beta, pp[vw].y, rr2[vw].y) : 0.0;
-                tot[vw] = wave_sum(fma(py, ay, px * ax));
-            }
-            double dsum = tot[0];
-#pragma unroll
-            for (int vw = 1; vw < 4; ++vw) dsum += tot[vw];
-            if (lane == 0) seg_tail[c] = dsum;
         }
     }
 }
@@ -713,6 +641,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gemv_ldsp(const double *__restri
 // Branch-free: every load is unconditional (clamped index, value dropped by a select), so that all of them -- up to
 // kMaxSplit pieces and the two elements of p -- are in flight together; loads behind a branch or in a loop of unknown
 // length are waited for one by one (seen in the ISA: s_waitcnt vmcnt(0) after each piece).
+constexpr int kMaxSplit = 8;
 __device__ __forceinline__ d2 chunk_pair(const double *__restrict__ parts, int split, long stride, int row, int Sr)
 {
     const int rc = row < Sr ? row : Sr - 2;                           // Sr is even and >= 2, slices are 16-B aligned
@@ -1877,8 +1806,6 @@ struct GemvArgs {
     hipEvent_t e0 = nullptr, e1 = nullptr;   // optional: bound to the dispatch (kernel begin / end)
     int split = 1;                           // one-round form only: column pieces per row group
     long ap_stride = 0;
-    unsigned *tickets = nullptr;             // COMBINE (experiment): arrival words, the Ap slice of the segment, its chunk partials
-    double *seg_ap = nullptr, *seg_tail = nullptr;
 };
 
 template <int R, int U, int MODE>
@@ -1889,30 +1816,19 @@ hipError_t launch_shape(const GemvPlan &pl, const GemvArgs &g, hipStream_t s)
                               g.row0, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol);
     else
         hipExtLaunchKernelGGL((k_gemv_colsplit<R, U, 4, MODE>), dim3(pl.grid / pl.split), dim3(256), 0, s, g.e0, g.e1, 0, g.A, g.lda,
-                              pl.ncols, g.rows, g.row0, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol, 1, 0L, (unsigned *)nullptr, (double *)nullptr, (double *)nullptr);
+                              pl.ncols, g.rows, g.row0, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol, 1, 0L);
     return hipGetLastError();
 }
 
 template <int R, int U, int MODE>
 hipError_t launch_light(const GemvPlan &pl, const GemvArgs &g, hipStream_t s)
 {
-    if (g.tickets) {   // the prefold folded into this launch by arrival tickets (experiment): the default multi-rank shape only
-        if constexpr (R == 8 && U == 2 && MODE == kFusedSingle) {
-            if (g.split < 2 || g.partials) return hipErrorInvalidValue;
-            hipExtLaunchKernelGGL((k_gemv_colsplit<R, U, 4, MODE, true, false, true>), dim3(pl.grid / pl.split * g.split), dim3(256), 0, s, g.e0, g.e1, 0, g.A, g.lda,
-                                  pl.ncols, g.rows, g.row0, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol, g.split, g.ap_stride,
-                                  g.tickets, g.seg_ap, g.seg_tail);
-            return hipGetLastError();
-        } else {
-            return hipErrorInvalidValue;
-        }
-    }
     if (g.partials)
         hipExtLaunchKernelGGL((k_gemv_colsplit<R, U, 4, MODE, true, true>), dim3(pl.grid / pl.split * g.split), dim3(256), 0, s, g.e0, g.e1, 0, g.A, g.lda,
-                              pl.ncols, g.rows, g.row0, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol, g.split, g.ap_stride, (unsigned *)nullptr, (double *)nullptr, (double *)nullptr);
+                              pl.ncols, g.rows, g.row0, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol, g.split, g.ap_stride);
     else   // nobody folds this launch's per-workgroup p.Ap partials (chunked exchange)
         hipExtLaunchKernelGGL((k_gemv_colsplit<R, U, 4, MODE, true, false>), dim3(pl.grid / pl.split * g.split), dim3(256), 0, s, g.e0, g.e1, 0, g.A, g.lda,
-                              pl.ncols, g.rows, g.row0, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol, g.split, g.ap_stride, (unsigned *)nullptr, (double *)nullptr, (double *)nullptr);
+                              pl.ncols, g.rows, g.row0, g.v, g.p_new, g.sv, g.Ap, g.partials, g.sc, g.k, g.tol, g.split, g.ap_stride);
     return hipGetLastError();
 }
 
@@ -1952,15 +1868,11 @@ hipError_t launch_gemv_plain(const GemvPlan &pl, const double *A, long lda, int 
 
 hipError_t launch_gemv_fused(const GemvPlan &pl, const double *A, long lda, int rows, int row0, const double *p_old,
                              double *p_new, SegView seg, double *Ap, double *partials, Scalars *sc, int k, double tol,
-                             hipStream_t s, hipEvent_t e_start, hipEvent_t e_stop, long ap_stride, unsigned *tickets,
-                             double *seg_ap, double *seg_tail)
+                             hipStream_t s, hipEvent_t e_start, hipEvent_t e_stop, long ap_stride)
 {
     GemvArgs g{A, lda, rows, row0, p_old, p_new, seg, Ap, partials, sc, k, tol, e_start, e_stop};
     g.split = pl.split;
     g.ap_stride = ap_stride;
-    g.tickets = tickets;
-    g.seg_ap = seg_ap;
-    g.seg_tail = seg_tail;
     if (pl.split > 1 && (!pl.light || ap_stride <= 0)) return hipErrorInvalidValue;
     return dispatch_gemv<kFusedSingle>(pl, g, s);
 }

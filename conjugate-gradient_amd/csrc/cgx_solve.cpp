@@ -182,8 +182,7 @@ cgx_status run_gemv_fused(cgx_ctx *ctx, Shard &s, int k)
         HIP_TRY(ctx, cgx::launch_gemv_fused(s.plan, s.A, ctx->lda, s.rows, s.row0, s.p[k & 1], s.p[(k + 1) & 1], s.rv,
                                             s.plan.split > 1 ? s.ap_parts : s.Ap(),
                                             (ctx->chunked && s.plan.light) ? nullptr : s.k1_part(),   // chunked: nobody folds K1's own partials
-                                            s.sc, k, ctx->tol, ctx->stream, e0, e1, ctx->seg_Sr,
-                                            s.tickets, s.tickets ? s.Ap() : nullptr, s.tickets ? s.tail() : nullptr));
+                                            s.sc, k, ctx->tol, ctx->stream, e0, e1, ctx->seg_Sr));
     if (m1) HIP_TRY(ctx, hipEventRecord(m1, ctx->stream));
     return CGX_OK;
 }
@@ -252,7 +251,6 @@ cgx_status enqueue_iteration(cgx_ctx *ctx, int k)
     // chunk of the slice into its tail (k_prefold_ap) -- that is what travels
     if (ctx->chunked)
         for (auto &s : ctx->shards)
-            if (!s.tickets)   // (experiment CGX_K1_COMBINE: K1 itself has written the slice and the chunk partials)
             HIP_TRY(ctx, cgx::launch_prefold_ap(s.plan.split > 1 ? s.ap_parts : s.Ap(), s.plan.split, ctx->seg_Sr, s.rows, ctx->seg_Sr,
                                                 s.p[(k + 1) & 1] + s.row0, s.Ap(), s.tail(), s.sc, st));
     CGX_TRY(gather_segments(ctx, true));                                                             // cg.cc:106

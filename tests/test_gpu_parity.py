@@ -641,34 +641,6 @@ def test_beyond_int_indexing(gpu_pkg, oracle, n, shard_counts):
         assert rel(xs[0][1]["residual_prev"], r["residual_prev"]) < 1e-10
 
 
-# ---- experiment: k_prefold_ap folded into K1 by arrival tickets (CGX_K1_COMBINE=1) ----------------------------------------
-@pytest.mark.parametrize("n,p,variant,iters", [(4096, 4, 10825, 60), (5000, 3, 10825, 40), (1000, 8, 10825, 30), (9, 4, 10825, 3),
-                                               (32768, 8, 0, 25)])
-def test_k1_with_the_prefold_folded_in_gives_the_same_bits(gpu_pkg, oracle, n, p, variant, iters):
-    """The (8,2) one-round K1 with 8 column pieces, once followed by k_prefold_ap and once combining the pieces and reducing the
-    chunk partials itself through arrival tickets (same order of additions by construction): bit-identical solves, uneven
-    partitions and partial last chunks / row groups included; and the oracle agrees."""
-    out = []
-    for combine in ("0", "1"):
-        os.environ["CGX_K1_COMBINE"] = combine
-        try:
-            with make(gpu_pkg, n, gpu_pkg.COMM_LOOPBACK, p, variant, max_iter=iters, tol=0.0) as s:
-                plan = s.gemv_plan(0)
-                x = np.zeros(n)
-                r = s.solve(x)
-                x2 = np.zeros(n)
-                r2 = s.solve(x2)                      # the tickets are back at zero: a second solve gives the same bits
-        finally:
-            os.environ.pop("CGX_K1_COMBINE", None)
-        assert np.array_equal(x, x2) and r["residual_prev"] == r2["residual_prev"]
-        out.append((x, r))
-    assert plan["split"] == 8 and plan["light"] == 1 and plan["R"] == 8 and plan["U"] == 2
-    (x0, r0), (x1, r1) = out
-    assert np.array_equal(x0, x1) and r0["residual_prev"] == r1["residual_prev"] and r0["x_norm"] == r1["x_norm"]
-    xo, ro = (oracle.solve_lap2d if n <= 8192 else oracle.solve_lap2d_banded)(n, iters, 0.0, p)
-    assert np.linalg.norm(x1 - xo) <= 1e-12 * np.linalg.norm(xo)
-
-
 # ---- command line -------------------------------------------------------------------------------------------------
 def test_cgsolver_cli_both_forms(gpu_pkg, mtx_path, tmp_path):
     exe = os.path.join(ROOT, "conjugate-gradient_amd", "cgsolver")
