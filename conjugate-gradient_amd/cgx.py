@@ -31,7 +31,7 @@ EXPORTS = [
     "cgx_probe_gemv", "cgx_probe_time_gemv", "cgx_probe_vector_ops", "cgx_probe_get_matrix_rows",
     "cgx_probe_get_source_term", "cgx_probe_set_fault_after", "cgx_probe_set_resident_limit",
     "cgx_probe_parse_matrix_market", "cgx_probe_p2p_mailbox_to_host", "cgx_probe_fill_matrix_hash",
-    "cgx_probe_set_p2p_epoch", "cgx_probe_get_p2p_epoch",
+    "cgx_probe_set_p2p_epoch", "cgx_probe_get_p2p_epoch", "cgx_probe_p2p_host_mailboxes",
 ]
 
 
@@ -134,6 +134,7 @@ def lib():
         L.cgx_probe_set_resident_limit.argtypes = [vp, C.c_int]
         L.cgx_probe_p2p_mailbox_to_host.argtypes = [vp]
         L.cgx_probe_fill_matrix_hash.argtypes = [vp, C.c_ulonglong, C.c_int, C.c_double]
+        L.cgx_probe_p2p_host_mailboxes.argtypes = [vp, C.c_char_p, C.c_int]
         L.cgx_probe_set_p2p_epoch.argtypes = [vp, C.c_int, C.c_ulonglong]
         L.cgx_probe_get_p2p_epoch.argtypes = [vp, C.c_int, C.POINTER(C.c_ulonglong)]
         L.cgx_probe_parse_matrix_market.argtypes = [C.c_char_p, C.c_int, ip, ip, ip, ip, ip, ip, dp, C.c_long, C.c_char_p, C.c_int]
@@ -395,6 +396,10 @@ class CGSolver:
     def _mailbox_to_host(self):
         """Test hook: the mailbox of a one-rank P2P context moves to pinned coherent host memory (exchange over PCIe)."""
         self._check(lib().cgx_probe_p2p_mailbox_to_host(self._h))
+
+    def _host_mailboxes(self, prefix, stage):
+        """Test hook: every rank's mailbox in POSIX shared host memory (stage 0: create own; barrier; stage 1: map the peers')."""
+        self._check(lib().cgx_probe_p2p_host_mailboxes(self._h, prefix.encode(), int(stage)))
 
     def _set_p2p_epoch(self, chan, value):
         """Test hook: move the epoch counter of a mailbox channel forward (same call on every rank, between two solves)."""

@@ -2,6 +2,9 @@
 // the allocation of the row-block shards (include/cgx.h "life cycle", "CGX_COMM_P2P wire-up", cgx_partition).
 #include "cgx_internal.h"
 
+#include <sys/mman.h>
+#include <fcntl.h>
+
 #include <algorithm>
 #include <cctype>
 #include <chrono>
@@ -630,7 +633,16 @@ cgx_status cgx_destroy(cgx_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     free_problem(ctx);
     if (ctx->comm && ctx->rccl) (void)ctx->rccl->CommDestroy(ctx->comm);
-    if (ctx->cfg.comm_mode == CGX_COMM_P2P) {
+    if (ctx->cfg.comm_mode == CGX_COMM_P2P && ctx->mailbox_shm) {
+        // test only (cgx_probe_p2p_host_mailboxes): shared host segments, registered with the runtime
+        for (int q = 0; q < ctx->nranks; ++q)
+            if (ctx->host_maps[q]) {
+                (void)hipHostUnregister(ctx->host_maps[q]);
+                (void)munmap(ctx->host_maps[q], ctx->mailbox_bytes);
+            }
+        (void)shm_unlink(("/" + ctx->shm_prefix + "_" + std::to_string(ctx->cfg.rank)).c_str());
+        if (ctx->d_p2p_err) (void)hipFree(ctx->d_p2p_err);
+    } else if (ctx->cfg.comm_mode == CGX_COMM_P2P) {
         for (int q = 0; q < ctx->nranks; ++q)
             if (q != ctx->cfg.rank && ctx->mv.base[q]) (void)hipIpcCloseMemHandle(ctx->mv.base[q]);
         if (ctx->mailbox) (void)(ctx->mailbox_on_host ? hipHostFree(ctx->mailbox) : hipFree(ctx->mailbox));

@@ -67,6 +67,11 @@ struct cgx_ctx {
     unsigned char *mailbox = nullptr;        // own fine-grained mailbox
     size_t mailbox_bytes = 0;
     bool mailbox_on_host = false;            // test only (cgx_probe_p2p_mailbox_to_host): the mailbox lives in pinned host memory
+    // test only (cgx_probe_p2p_host_mailboxes): EVERY rank's mailbox is a POSIX shared-memory segment registered with the
+    // runtime; host_maps[q] = this process's mapping of rank q's segment (own included), nullptr otherwise
+    bool mailbox_shm = false;
+    std::string shm_prefix;
+    void *host_maps[cgx::kMaxRanks] = {nullptr};
     bool p2p_ready = false;                  // peers' mailboxes are mapped
     cgx::MailboxView mv{};
     unsigned long long p2p_epoch[cgx::kP2pChannels] = {0, 0, 0};

@@ -1,6 +1,11 @@
 // cgx_probe.cpp -- kernel probes of include/cgx.h: the individual hot ops through the C ABI, for the parity tests.
 #include "cgx_internal.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <cctype>
 #include <chrono>
@@ -202,6 +207,73 @@ cgx_status cgx_probe_get_p2p_epoch(cgx_ctx *ctx, int chan, unsigned long long *v
 {
     if (!ctx || !value || ctx->cfg.comm_mode != CGX_COMM_P2P || chan < 0 || chan >= cgx::kP2pChannels) return CGX_ERR_BAD_ARG;
     *value = ctx->p2p_epoch[chan];
+    return CGX_OK;
+}
+
+// TEST ONLY: the mailboxes of a MULTI-rank P2P job in POSIX shared HOST memory.  With device mailboxes and every rank on
+// one GPU (all a one-GPU box offers) a "peer's" mailbox is this GPU's own HBM behind its own L2; here every store of every
+// rank leaves the GPU over PCIe into host DRAM and every poll and load of every rank comes back over it, between separate
+// processes: memory that is remote for every party, written by one process and polled by another.
+//   stage 0: create, size and zero this rank's segment <prefix>_<rank>, register it with the runtime, make it THE mailbox;
+//   -- launcher barrier (every segment exists) --
+//   stage 1: map and register every peer's segment.  Replaces cgx_p2p_export / cgx_p2p_import; before any problem is set.
+cgx_status cgx_probe_p2p_host_mailboxes(cgx_ctx *ctx, const char *prefix, int stage)
+{
+    if (!ctx || !prefix || ctx->cfg.comm_mode != CGX_COMM_P2P || !ctx->shards.empty() || (stage != 0 && stage != 1))
+        return fail(ctx, CGX_ERR_BAD_ARG, "cgx_probe_p2p_host_mailboxes: a P2P context without a problem, stage 0 or 1");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int me = ctx->cfg.rank;
+    auto map_segment = [&](int q, bool create, void **out) -> cgx_status {
+        const std::string name = "/" + std::string(prefix) + "_" + std::to_string(q);
+        const int fd = shm_open(name.c_str(), create ? (O_CREAT | O_RDWR) : O_RDWR, 0600);
+        if (fd < 0) return fail(ctx, CGX_ERR_IO, "shm_open(" + name + ") failed");
+        if (create && ftruncate(fd, (off_t)ctx->mailbox_bytes) != 0) {
+            close(fd);
+            return fail(ctx, CGX_ERR_IO, "ftruncate(" + name + ") failed");
+        }
+        void *ptr = mmap(nullptr, ctx->mailbox_bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        close(fd);
+        if (ptr == MAP_FAILED) return fail(ctx, CGX_ERR_IO, "mmap(" + name + ") failed");
+        if (create) memset(ptr, 0, ctx->mailbox_bytes);
+        const hipError_t e = hipHostRegister(ptr, ctx->mailbox_bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+        if (e != hipSuccess) {
+            munmap(ptr, ctx->mailbox_bytes);
+            return fail(ctx, CGX_ERR_HIP, std::string("hipHostRegister(") + name + "): " + hipGetErrorString(e));
+        }
+        *out = ptr;
+        return CGX_OK;
+    };
+    auto device_view = [&](void *host, unsigned char **dev) -> cgx_status {
+        void *d = nullptr;
+        HIP_TRY(ctx, hipHostGetDevicePointer(&d, host, 0));
+        *dev = static_cast<unsigned char *>(d);
+        return CGX_OK;
+    };
+    if (stage == 0) {
+        if (ctx->mailbox_shm || ctx->mailbox_on_host) return fail(ctx, CGX_ERR_BAD_ARG, "the mailbox has already been moved");
+        void *mine = nullptr;
+        CGX_TRY(map_segment(me, true, &mine));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->mailbox);
+        ctx->host_maps[me] = mine;
+        ctx->mailbox_shm = true;
+        ctx->shm_prefix = prefix;
+        unsigned char *dev = nullptr;
+        CGX_TRY(device_view(mine, &dev));
+        ctx->mailbox = dev;
+        ctx->mv.base[me] = dev;
+        ctx->p2p_ready = ctx->nranks == 1;
+        return CGX_OK;
+    }
+    if (!ctx->mailbox_shm) return fail(ctx, CGX_ERR_BAD_ARG, "stage 1 before stage 0");
+    for (int q = 0; q < ctx->nranks; ++q) {
+        if (q == me || ctx->host_maps[q]) continue;
+        void *ptr = nullptr;
+        CGX_TRY(map_segment(q, false, &ptr));
+        ctx->host_maps[q] = ptr;
+        CGX_TRY(device_view(ptr, &ctx->mv.base[q]));
+    }
+    ctx->p2p_ready = true;
     return CGX_OK;
 }
 

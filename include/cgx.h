@@ -231,6 +231,11 @@ cgx_status  cgx_probe_parse_matrix_market(const char *path, int threads, int *m,
 /* TEST ONLY: moves the mailbox of a ONE-rank CGX_COMM_P2P context (no problem set yet) into pinned, coherent host memory, so
  * that every store, poll and load of the exchange crosses PCIe: the system-scope path outside this GPU's HBM and L2. */
 cgx_status  cgx_probe_p2p_mailbox_to_host(cgx_ctx *ctx);
+/* TEST ONLY: the mailboxes of a multi-rank CGX_COMM_P2P job in POSIX shared HOST memory (segments <prefix>_<rank>), so that
+ * the stores, polls and loads of EVERY rank cross PCIe between separate processes -- the closest a one-GPU box offers to
+ * peers whose memory is remote.  Replaces cgx_p2p_export / cgx_p2p_import: stage 0 creates this rank's segment and makes it
+ * the mailbox; after a launcher barrier stage 1 maps every peer's.  Before any problem is set. */
+cgx_status  cgx_probe_p2p_host_mailboxes(cgx_ctx *ctx, const char *prefix, int stage);
 /* Test hook for the co-residency guard of CGX_COMM_P2P's fused update kernel (its workgroups wait for each other inside the
  * kernel, so its grid must not exceed what the device keeps resident: occupancy x CUs, queried from the runtime when a
  * problem is set): workgroups > 0 replaces the queried bound for the problems set afterwards, 0 restores it. */

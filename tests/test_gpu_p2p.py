@@ -94,6 +94,27 @@ def test_p2p_epoch_boundaries(tmp_path, world, n, iters, port):
             assert q["end"] == q["start"] + iters + (0 if form == "tagged" else 2), (form, q)
 
 
+@pytest.mark.parametrize("world,n,iters,tagged,port", [(2, 3000, 60, 0, 29761), (2, 3000, 60, 1, 29762), (3, 2048, 80, 0, 29763), (3, 2048, 80, 1, 29764)])
+def test_p2p_processes_over_shared_host_memory(tmp_path, world, n, iters, tagged, port):
+    """The multi-process exchange with every rank's mailbox in POSIX shared HOST memory: all stores, polls and loads of all
+    ranks cross PCIe between separate processes -- memory that is remote for every party, unlike the device mailboxes of a
+    one-GPU rehearsal, which are this GPU's own HBM.  Self-test green, solves bit-identical to the device-mailbox run on every
+    rank, both forms of the fused exchange; no segment is left behind in /dev/shm."""
+    out = tmp_path / "hostmem.json"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "p2p_hostmem_worker.py"),
+           str(n), str(iters), str(out), str(tagged)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=420,
+                       env=dict(os.environ, OMP_NUM_THREADS="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    v = json.load(open(out))
+    assert v["selftest_device"] and v["selftest_host"], v
+    assert v["host_equals_device_on_every_rank"] and v["ranks_agree"] and v["second_solve_same_bits"], v
+    assert v["k"] == iters and v["dx_oracle"] < 1e-12, v
+    assert not [f for f in os.listdir("/dev/shm") if f.startswith("cgx_test_%d_" % port)]
+    print("loop seconds: device mailboxes %.4f, shared host memory %.4f (world %d, tagged %d)" % (v["loop_s_device"], v["loop_s_host"], world, tagged))
+
+
 def _check_p2p(v, n):
     assert v["selftest_ok"], v
     assert v["ranks_agree"], v
