@@ -622,6 +622,16 @@ cgx_status cgx_p2p_selftest(cgx_ctx *ctx, int rounds, int *ok)
                 if (sums[(size_t)b] != total) good = false;
         }
     }
+    if (good) {
+        // Close the self-test the way a solve ends: one exchange on channel 2.  A rank finishes it only after every peer has
+        // pushed its channel-2 data, which a peer does, in stream order, after its last kernel of the second half -- so when this
+        // call returns, every peer is done READING its self-test slots and the next layout (a problem's) may be written into any
+        // mailbox.  The launcher's agreement on `ok` decides what happens next; it is no longer what makes the re-layout safe.
+        // (If a peer's self-test failed it never gets here, and this wait ends at its bound: then the test has failed here too.)
+        CGX_TRY(p2p_allgather(ctx, 2, dsrc, cgx::kSlots, ddst, cgx::kSlots, 1));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        if (check_p2p_error(ctx) != CGX_OK) good = false;
+    }
     *ok = good ? 1 : 0;
     return CGX_OK;
 }

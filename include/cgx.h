@@ -152,8 +152,9 @@ cgx_status  cgx_get_gemv_plan(const cgx_ctx *ctx, int local_shard, int out[CGX_G
 /* export: this rank's mailbox as an IPC handle.  import: all ranks' handles, rank order (nranks * 64 bytes),
  * gathered by the launcher (torch.distributed, MPI_Allgather, pipes ...).  selftest: `rounds` all-gathers of
  * a known pattern, verified on every rank; *ok = 0 on any mismatch or expired wait (then use CGX_COMM_RCCL).
- * The launcher must agree on `ok` across ranks (all-reduce MIN) before anything else is exchanged: that also is the
- * barrier which guarantees every rank has finished reading its self-test slots before the mailbox is re-laid-out. */
+ * The launcher must agree on `ok` across ranks (all-reduce MIN) before anything else is exchanged: every rank must take the
+ * same decision.  (That agreement is not what makes the re-layout of the mailbox for a problem safe: a passing self-test
+ * ends with an exchange on the scalar channel, after which every peer has finished reading its self-test slots.) */
 cgx_status  cgx_p2p_export(cgx_ctx *ctx, unsigned char out[CGX_IPC_HANDLE_BYTES]);
 cgx_status  cgx_p2p_import(cgx_ctx *ctx, const unsigned char *handles);
 cgx_status  cgx_p2p_selftest(cgx_ctx *ctx, int rounds, int *ok);

@@ -40,6 +40,7 @@ def main():
         s.p2p_import(b"".join(bytes(t.tolist()) for t in allh))
         dist.barrier()
         ok = s.p2p_selftest(8)
+        dist.barrier()                          # launchers agree on `ok` before the next layout (include/cgx.h)
         s.generate_lap2d_matrix(n)
         s.set_max_iter(iters)
         s.tolerance(0.0)

@@ -37,6 +37,7 @@ def main():
             s._host_mailboxes(prefix, 1)
         dist.barrier()
         ok = s.p2p_selftest(16)
+        dist.barrier()                          # launchers agree on `ok` before the next layout (include/cgx.h)
         s.generate_lap2d_matrix(n)
         s.set_max_iter(iters)
         s.tolerance(0.0)

@@ -33,6 +33,7 @@ def main():
     s.p2p_import(b"".join(bytes(t.tolist()) for t in allh))
     dist.barrier()
     ok = s.p2p_selftest(16)
+    dist.barrier()                          # launchers agree on `ok` before the next layout (include/cgx.h)
     s.generate_lap2d_matrix(n)
     s.set_max_iter(max_iter)
     tol = 0.0 if n < 16 else 1e-10          # tiny systems: do not let rounding decide who converges first
