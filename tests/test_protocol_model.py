@@ -5,11 +5,12 @@ import struct
 
 import numpy as np
 
-NAN_HI = 0xFFF80000
+M = 2 ** 32 - 1
 
 
 def tag_of(epoch):
-    return (epoch & 0xFFFFFFFF) ^ NAN_HI
+    """p2p_tag (cgx_kernels.hip, round 4): 1 + epoch mod (2^32 - 1) -- 1 ... 2^32 - 1, never 0."""
+    return epoch % M + 1
 
 
 def pack(value, tag):
@@ -27,7 +28,7 @@ def accept(w0, w1, tag):
 def test_round_trip_is_bit_exact():
     rng = np.random.default_rng(0)
     vals = list(rng.standard_normal(200) * 10.0 ** rng.integers(-300, 300, 200)) + [0.0, -0.0, np.inf, -np.inf, 5e-324, 1.7976931348623157e308]
-    for e in (1, 2, 12345, 2**19 - 1, 2**31, 2**32 - 1, 2**32 + 5):
+    for e in (1, 2, 12345, 2**19 - 1, 0xFFF80000, 2**31, 2**32 - 2, 2**32 - 1, 2**32 + 5, 2 * M):
         t = tag_of(e)
         for v in vals:
             got = accept(*pack(float(v), t), t)
@@ -45,27 +46,31 @@ def test_a_torn_or_stale_pair_is_never_accepted():
     o0, o1 = pack(-7.5, old)
     assert accept(n0, n1, new) == 3.25
     assert accept(n0, o1, new) is None and accept(o0, n1, new) is None and accept(o0, o1, new) is None
-    assert accept(0, 0, new) is None                      # a zero-filled mailbox holds no valid word (tag 0 is epoch 0xFFF80000)
-    assert tag_of(0xFFF80000) == 0
+    assert accept(0, 0, new) is None
 
 
-def test_tags_are_a_bijection_of_the_low_32_epoch_bits():
-    es = np.arange(0, 1 << 20, 4099, dtype=np.uint64)
-    tags = {tag_of(int(e)) for e in es}
-    assert len(tags) == len(es)
-    assert tag_of(5) == tag_of(5 + 2**32) and tag_of(5) != tag_of(6)      # collisions only 2^32 epochs apart
+def test_a_zero_filled_slot_is_never_accepted_at_any_epoch():
+    """The mailbox is zero-filled at creation and the tagged region again whenever it is laid out anew: no tag is 0 -- also not
+    at the epochs where round 3's tag (epoch XOR 0xFFF80000) was, nor where the 32-bit tag wraps."""
+    for e in (1, 2, 2 ** 19, 0xFFF80000, M - 1, M, M + 1, 2 ** 32, 2 * M, 2 * M + 1, 3 * M - 1, 2 ** 63):
+        t = tag_of(e)
+        assert 1 <= t <= M
+        assert accept(0, 0, t) is None and accept(*pack(1.5, t), t) == 1.5
 
 
-def test_no_finite_double_left_in_a_slot_passes_for_a_tagged_word_of_the_first_2_19_epochs():
-    """The set-up phases store plain doubles into the same slots.  A plain double's upper 32 bits equal a tag of an epoch below
-    2^19 only if they lie in [0xFFF80000, 0xFFFFFFFF]: sign 1, exponent all ones, top mantissa bit 1 -- a quiet NaN."""
-    for e in (1, 2, 1000, 2**19 - 1):
-        hi = tag_of(e)
-        assert 0xFFF80000 <= hi <= 0xFFFFFFFF
-        for lo in (0, 1, 0xFFFFFFFF):
-            v = struct.unpack("<d", struct.pack("<Q", (hi << 32) | lo))[0]
-            assert np.isnan(v)
-    rng = np.random.default_rng(1)
-    finite = rng.standard_normal(100000) * 10.0 ** rng.integers(-300, 300, 100000)
-    his = (finite.view(np.uint64) >> np.uint64(32)).astype(np.uint64)
-    assert not np.any(his >= np.uint64(0xFFF80000))
+def test_the_two_epochs_that_share_a_position_never_share_a_tag():
+    """A position is rewritten in every epoch of its parity, so the newest stale word a reader can meet is that of epoch e - 2;
+    the tags of e and e - 2 (and e - 1, e - 4) differ for every e, across the wrap of the tag as well."""
+    for base in (2, 1000, 2 ** 19, 0xFFF80000, M, 2 ** 32, 2 * M, 7 * M):
+        for e in range(base - 6, base + 7):
+            if e < 4:
+                continue
+            assert len({tag_of(e), tag_of(e - 1), tag_of(e - 2), tag_of(e - 4)}) == 4, e
+            stale = pack(-7.5, tag_of(e - 2))
+            assert accept(*stale, tag_of(e)) is None
+
+
+def test_tags_repeat_only_a_whole_period_apart():
+    es = np.arange(1, 1 << 22, 4099, dtype=np.uint64)
+    assert len({tag_of(int(e)) for e in es}) == len(es)
+    assert tag_of(5) == tag_of(5 + M) and tag_of(5) != tag_of(5 + 2 ** 32) and tag_of(5) != tag_of(6)
