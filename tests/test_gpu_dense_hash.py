@@ -59,7 +59,7 @@ def test_fill_needs_a_dense_problem(gpu_pkg):
             s.probe_fill_matrix_hash(1)
 
 
-@pytest.mark.parametrize("n,p", [(32768, 1), (32768, 8), (46340, 8), (46340, 1)])
+@pytest.mark.parametrize("n,p", [(32768, 1), (32768, 8), (46340, 8), (46340, 1), (32768, 4), (32768, 2), (23170, 2), (16384, 1)])
 def test_gemv_dense_hash_sampled_rows_at_baseline_sizes(gpu_pkg, oracle, n, p):
     """cgx_probe_gemv on the hash matrix at N = 32768 (one block of 8 GiB; 8 row blocks) and N = 46340 (8 uneven row blocks;
     one block of 17 GB): >= 256 sampled rows against oracle.gemv of the rebuilt rows -- first and last row of every block,

@@ -22,7 +22,11 @@ while time.time() - t0 < budget:
     iters = max(1, min(iters, n // 2))   # past ~n iterations the recurrence only moves rounding noise
     every = int(rng.choice([0, 1, 3, 16]))
     x0 = rng.standard_normal(n) if rng.integers(0, 2) else np.zeros(n)
-    A = O.generate_lap2d(n)
+    # a third of the dense cases: the hash matrix (every element a different number, symmetric, dominant diagonal: SPD) filled
+    # on the device by the test probe instead of the generator's five diagonals
+    hashed = (not banded) and n >= 8 and rng.integers(0, 3) == 0
+    hseed, hdiag = int(rng.integers(1, 2 ** 62)), 1.03 * 2.0 * (n / 3.0) ** 0.5 + 1.0
+    A = O.hash_rows(n, 0, n, hseed, True, hdiag) if hashed else O.generate_lap2d(n)
     b = O.init_source_term(n)
     if rng.integers(0, 3) == 0:
         b = rng.standard_normal(n)
@@ -36,14 +40,20 @@ while time.time() - t0 < budget:
         for (bd, v, PP) in ((banded, variant, P), (banded, 30001 if banded else 0, P), (False, 0, P), (banded, variant, 1), (banded, variant, 2), (banded, variant, 4)):
             with pkg.CGSolver(comm_mode=pkg.COMM_LOOPBACK if PP > 1 else pkg.COMM_SELF, nranks=PP, gemv_variant=v, check_every=every,
                               matrix_format=pkg.MATRIX_BANDED if bd else pkg.MATRIX_DENSE) as s:
-                s.generate_lap2d_matrix(n); s.set_source_term(b); s.set_max_iter(iters); s.tolerance(0.0)
+                s.generate_lap2d_matrix(n)
+                if hashed and not bd:
+                    s.probe_fill_matrix_hash(hseed, symmetric=True, diag=hdiag)
+                s.set_source_term(b); s.set_max_iter(iters); s.tolerance(0.0)
                 x = x0.copy(); r = s.solve(x)
             xo2, ro2 = O.solve(A, b, x0, iters, 0.0, PP)
             print("banded=%d variant=%d P=%d: err vs oracle(P) %.3e  res %r / %r  x0 zero=%s" % (bd, v, PP, np.linalg.norm(x - xo2) / np.linalg.norm(xo2), r["residual_prev"], ro2["residual_prev"], not x0.any()), flush=True)
         sys.exit(0)
     with pkg.CGSolver(comm_mode=pkg.COMM_LOOPBACK if P > 1 else pkg.COMM_SELF, nranks=P, gemv_variant=variant,
                       check_every=every, matrix_format=pkg.MATRIX_BANDED if banded else pkg.MATRIX_DENSE) as s:
-        s.generate_lap2d_matrix(n); s.set_source_term(b); s.set_max_iter(iters); s.tolerance(0.0)
+        s.generate_lap2d_matrix(n)
+        if hashed:
+            s.probe_fill_matrix_hash(hseed, symmetric=True, diag=hdiag)
+        s.set_source_term(b); s.set_max_iter(iters); s.tolerance(0.0)
         x = x0.copy(); r = s.solve(x)
     xo, ro = O.solve(A, b, x0, iters, 0.0, P)
     nx = np.linalg.norm(xo)
@@ -58,8 +68,8 @@ while time.time() - t0 < budget:
         xo3, ro3 = O.solve(A, b, x0, iters, 0.0, P)
         print("oracle again: residual %r (first %r), |dx oracle-oracle| %.3e, MXCSR 0x%x, case %d" % (
             ro3["residual_prev"], ro["residual_prev"], np.linalg.norm(xo3 - xo), O.fp_state(), cases), flush=True)
-        print("MISMATCH n=%d P=%d banded=%d variant=%d iters=%d every=%d err=%.3e res %r vs %r" %
-              (n, P, banded, variant, iters, every, err, r["residual_prev"], ro["residual_prev"]), flush=True)
+        print("MISMATCH n=%d P=%d banded=%d hashed=%d variant=%d iters=%d every=%d err=%.3e res %r vs %r" %
+              (n, P, banded, hashed, variant, iters, every, err, r["residual_prev"], ro["residual_prev"]), flush=True)
         # Everything needed to analyse the case offline goes to a file: the inputs (the matrix by its rule: generate_lap2d(n)),
         # what the GPU returned, what the oracle returned the first and the second time, the scalars of all three and the
         # oracle's floating-point state.  (Round 3's one disagreement, profiles/r03_fuzz_long.txt, could only be replayed, and
@@ -69,9 +79,12 @@ while time.time() - t0 < budget:
         path = os.path.join(out_dir, "fuzz_mismatch_seed%s_case%d_n%d_P%d.npz" % (sys.argv[2] if len(sys.argv) > 2 else "0", cases, n, P))
         with pkg.CGSolver(comm_mode=pkg.COMM_LOOPBACK if P > 1 else pkg.COMM_SELF, nranks=P, gemv_variant=variant,
                           check_every=every, matrix_format=pkg.MATRIX_BANDED if banded else pkg.MATRIX_DENSE) as s:
-            s.generate_lap2d_matrix(n); s.set_source_term(b); s.set_max_iter(iters); s.tolerance(0.0)
+            s.generate_lap2d_matrix(n)
+            if hashed:
+                s.probe_fill_matrix_hash(hseed, symmetric=True, diag=hdiag)
+            s.set_source_term(b); s.set_max_iter(iters); s.tolerance(0.0)
             x_again = x0.copy(); r_again = s.solve(x_again)
-        np.savez(path, matrix_rule="generate_lap2d(%d)" % n, n=n, P=P, banded=banded, variant=variant, iters=iters, check_every=every,
+        np.savez(path, matrix_rule=("hash_rows(%d, seed %d, symmetric, diag %r)" % (n, hseed, hdiag)) if hashed else "generate_lap2d(%d)" % n, n=n, P=P, banded=banded, variant=variant, iters=iters, check_every=every,
                  b=b, x0=x0, x_gpu=x, x_gpu_again=x_again, x_oracle_first=xo, x_oracle_again=xo3,
                  scalars_gpu=np.array([r["residual_prev"], r["x_norm"], r["rel_residual"]]),
                  scalars_gpu_again=np.array([r_again["residual_prev"], r_again["x_norm"], r_again["rel_residual"]]),
@@ -81,6 +94,7 @@ while time.time() - t0 < budget:
         print("case dumped to %s (GPU again bit-identical: %s, oracle again bit-identical: %s)" % (
             path, np.array_equal(x, x_again), np.array_equal(xo, xo3)), flush=True)
         sys.exit(1)
+    nhashed = globals().get("nhashed", 0) + (1 if hashed else 0)
     if cases % 200 == 0:
-        print("%d cases ok, worst ||dx||/||x|| = %.2e, %.0f s" % (cases, worst, time.time() - t0), flush=True)
-print("done: %d cases ok, worst ||dx||/||x|| = %.2e" % (cases, worst))
+        print("%d cases ok (%d on the hash matrix), worst ||dx||/||x|| = %.2e, %.0f s" % (cases, nhashed, worst, time.time() - t0), flush=True)
+print("done: %d cases ok (%d on the hash matrix), worst ||dx||/||x|| = %.2e" % (cases, globals().get("nhashed", 0), worst))
