@@ -2,7 +2,7 @@
 # Long soak of the fused exchange (both forms) with real processes sharing one MI355X; every line of progress goes to
 # gpurun_out/r03_soak_long.txt.  About 15 minutes.
 R=$(cd "$(dirname "$0")/.." && pwd)
-OUT=$R/gpurun_out/r03_soak_long.txt
+OUT=$R/gpurun_out/${SOAK_OUT:-r03_soak_long.txt}
 : > $OUT
 export MASTER_ADDR=127.0.0.1 OMP_NUM_THREADS=1
 TR="python3 -m torch.distributed.run --nnodes=1 --master-addr 127.0.0.1"
