@@ -356,3 +356,69 @@ def test_hash_matrix_with_dominant_diagonal_is_spd(oracle):
     assert w[0] > 0.0 and w[-1] / w[0] < 400.0
     x, r = oracle.solve(A, oracle.init_source_term(n), max_iter=n, tol=1e-10)
     assert r["converged"] and r["rel_residual"] < 1e-11
+
+
+# ---- the third-party arithmetic: the same recurrence through a real OpenBLAS -----------------------------------------------
+def _solve_through_openblas(A, b, max_iter, tol, psize=1):
+    """code/MPI/cg.cc:38-156 once more, with the three BLAS calls of the reference (cblas_dgemv cg.cc:80,101,146; cblas_ddot
+    :91,105,116; cblas_daxpy :82,110,113,128) made through the OpenBLAS that numpy / scipy bundle (scipy.linalg.blas: the
+    Fortran entry points of the same kernels the reference's cblas_* wrappers call; the reference used OpenBLAS 0.3.10,
+    figures/gprof.png) -- row blocks as partition_matrix cuts them, the Allreduce sums in rank order."""
+    from scipy.linalg import blas
+    n = b.size
+    starts, counts = [0], [n]
+    if psize > 1:
+        n_loc = n // psize
+        starts = [q * n_loc for q in range(psize)]
+        counts = [n_loc] * (psize - 1) + [n - (psize - 1) * n_loc]
+    blocks = [np.asfortranarray(A[s:s + c].T) for s, c in zip(starts, counts)]      # A_block^T column-major = A_block row-major
+    gemv = lambda v: np.concatenate([blas.dgemv(1.0, At, v, trans=1) for At in blocks])   # noqa: E731
+    dot = lambda u, v: sum(blas.ddot(u[s:s + c], v[s:s + c]) for s, c in zip(starts, counts))   # noqa: E731
+    x = np.zeros(n)
+    r = b - gemv(x)                                              # cg.cc:79-82
+    p = r.copy()                                                 # cg.cc:85
+    rsold = dot(r, r)                                            # cg.cc:91-92
+    k = 0
+    while k < max_iter:
+        Ap = gemv(p)                                             # cg.cc:100-102
+        conj = dot(p, Ap)                                        # cg.cc:105-106
+        alpha = rsold / max(conj, rsold * 1e-14)                 # cg.cc:107
+        x = blas.daxpy(p, x, a=alpha)                            # cg.cc:110
+        r = blas.daxpy(Ap, r, a=-alpha)                          # cg.cc:113
+        rsnew = dot(r, r)                                        # cg.cc:116-117
+        if np.sqrt(rsnew) < tol:                                 # cg.cc:120-121
+            break
+        beta = rsnew / rsold                                     # cg.cc:124
+        p = blas.daxpy(p, r.copy(), a=beta)                      # cg.cc:127-129: p = r + beta p
+        rsold = rsnew                                            # cg.cc:132
+        k += 1
+    return x, k, float(np.sqrt(rsold))
+
+
+@pytest.mark.parametrize("n,max_iter,psize", [(2048, 200, 1), (2048, 200, 4), (4096, 200, 1), (4096, 50, 8), (3000, 150, 3), (1024, None, 1),
+                                              (1000, None, 3)])
+def test_oracle_agrees_with_the_recurrence_through_a_real_openblas(oracle, reference_probe, n, max_iter, psize):
+    """The reference's GEMV / dot / axpy live in OpenBLAS (unpinned; 0.3.10 in figures/gprof.png), whose summation order is not
+    the oracle's.  The same recurrence driven through the OpenBLAS kernels numpy / scipy bundle must land on the oracle's
+    result to the tolerance DESIGN.md states for parity (x to 1e-12, residual to 1e-10 relative at a fixed iteration count),
+    and on the reference's own recorded numbers where the survey recorded this run."""
+    A = oracle.generate_lap2d(n)
+    b = oracle.init_source_term(n)
+    it = n if max_iter is None else max_iter
+    xb, kb, resb = _solve_through_openblas(A, b, it, 1e-10, psize)
+    xo, ro = oracle.solve(A, b, max_iter=it, tol=1e-10, psize=psize)
+    if max_iter is None:
+        assert ro["converged"] and abs(kb - ro["iterations"]) <= 0.15 * ro["iterations"]       # k is not a stable observable
+        assert np.linalg.norm(xb - xo) <= 1e-10 * np.linalg.norm(xo)
+    else:
+        assert kb == ro["iterations"] == max_iter
+        assert np.linalg.norm(xb - xo) <= 1e-12 * np.linalg.norm(xo)
+        assert abs(resb - ro["residual_prev"]) <= 1e-10 * ro["residual_prev"]
+    rows = [q for q in reference_probe["generated"] if q["n"] == n and q["max_iter"] == max_iter and q["ranks"] == psize]
+    if n != 3000:
+        assert rows, "a run the survey recorded from the compiled reference"
+        assert abs(np.linalg.norm(xb) - rows[0]["x_norm"]) <= 1e-6 * rows[0]["x_norm"]
+        if max_iter is not None:
+            assert kb == rows[0]["k"] and abs(resb - rows[0]["residual"]) <= 1e-6 * rows[0]["residual"]
+        else:
+            assert abs(kb - rows[0]["k"]) <= 0.15 * rows[0]["k"]
