@@ -8,12 +8,15 @@ Tolerances (fp64; north_star's "residual within 1e-10 of reference" read as in S
 """
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if os.path.join(ROOT, "tests") not in sys.path:
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
 def rel(a, b):
@@ -639,6 +642,24 @@ def test_beyond_int_indexing(gpu_pkg, oracle, n, shard_counts):
     for x, r in xs[1:]:
         assert np.linalg.norm(xs[0][0] - x) / np.linalg.norm(xs[0][0]) < 1e-13
         assert rel(xs[0][1]["residual_prev"], r["residual_prev"]) < 1e-10
+
+
+# ---- a second checker: the recurrence through a real OpenBLAS -------------------------------------------------------------
+@pytest.mark.parametrize("n,iters,p", [(8192, 200, 1), (8192, 200, 4), (10000, 150, 3)])
+def test_hip_path_against_the_recurrence_through_a_real_openblas(gpu_pkg, oracle, n, iters, p):
+    """Not the oracle's loops but OpenBLAS's own dgemv / ddot / daxpy (the library family the reference linked; scipy bundles
+    0.3.29) driving cg.cc:38-156 on the host (tests/test_oracle.py::_solve_through_openblas): the HIP path must land on that
+    result as it lands on the oracle's -- x to 1e-12, residual to 1e-10 relative."""
+    from test_oracle import _solve_through_openblas
+    A = oracle.generate_lap2d(n)
+    b = oracle.init_source_term(n)
+    xb, kb, resb = _solve_through_openblas(A, b, iters, 0.0, p)
+    with make(gpu_pkg, n, None if p == 1 else gpu_pkg.COMM_LOOPBACK, p, max_iter=iters, tol=0.0) as s:
+        x = np.zeros(n)
+        r = s.solve(x)
+    assert r["iterations"] == kb == iters
+    assert np.linalg.norm(x - xb) <= 1e-12 * np.linalg.norm(xb)
+    assert rel(r["residual_prev"], resb) < 1e-10
 
 
 # ---- command line -------------------------------------------------------------------------------------------------
