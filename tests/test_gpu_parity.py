@@ -645,7 +645,7 @@ def test_beyond_int_indexing(gpu_pkg, oracle, n, shard_counts):
 
 
 # ---- a second checker: the recurrence through a real OpenBLAS -------------------------------------------------------------
-@pytest.mark.parametrize("n,iters,p", [(8192, 200, 1), (8192, 200, 4), (10000, 150, 3)])
+@pytest.mark.parametrize("n,iters,p", [(8192, 200, 1), (8192, 200, 4), (10000, 150, 3), (32768, 500, 1)])   # the last: BASELINE configs[2]
 def test_hip_path_against_the_recurrence_through_a_real_openblas(gpu_pkg, oracle, n, iters, p):
     """Not the oracle's loops but OpenBLAS's own dgemv / ddot / daxpy (the library family the reference linked; scipy bundles
     0.3.29) driving cg.cc:38-156 on the host (tests/test_oracle.py::_solve_through_openblas): the HIP path must land on that
