@@ -181,3 +181,42 @@ def test_committed_traffic_rows_name_the_kernel_form_they_were_collected_on():
         assert 1.0 <= r["traffic_over_algorithmic"] < 1.01 and r["launches_sampled"] >= 100
         seen.add((r["n"], r["nranks"]))
     assert {(32768, 1), (32768, 2), (32768, 4), (32768, 8), (16384, 1)} <= seen
+
+
+def test_a_counter_pass_in_flight_is_ended_with_its_whole_process_group(tmp_path):
+    """the rocprofv3 child of live_pmc_traffic (and the bench.py under it, which holds a matrix on the GPU) runs in
+    a process group of its own that the stop paths (timeout, watchdog, SIGTERM) know: stop_launched() ends the group, the
+    grandchild included."""
+    import bench
+    marker = tmp_path / "grandchild.pid"
+    # a child that starts a grandchild and waits: the shape of `rocprofv3 -- python bench.py`
+    script = "import subprocess, sys, time\np = subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(600)'])\nopen(%r, 'w').write(str(p.pid))\ntime.sleep(600)\n" % str(marker)
+    proc = subprocess.Popen([sys.executable, "-c", script], start_new_session=True)
+    bench.LAUNCHED["extra"] = proc
+    try:
+        for _ in range(100):
+            if marker.exists() and marker.read_text():
+                break
+            time.sleep(0.05)
+        grandchild = int(marker.read_text())
+        t0 = time.time()
+        bench.stop_launched()
+        assert proc.poll() is not None and time.time() - t0 < 20
+        for _ in range(100):
+            try:
+                os.kill(grandchild, 0)
+            except ProcessLookupError:
+                break
+            # a zombie of a dead process still answers kill(0) until init reaps it: look at its state
+            try:
+                if open("/proc/%d/stat" % grandchild).read().split()[2] == "Z":
+                    break
+            except FileNotFoundError:
+                break
+            time.sleep(0.05)
+        else:
+            raise AssertionError("the grandchild of the counter pass survived stop_launched()")
+    finally:
+        bench.LAUNCHED["extra"] = None
+        if proc.poll() is None:
+            proc.kill()
