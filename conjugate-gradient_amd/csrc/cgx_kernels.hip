@@ -1277,12 +1277,17 @@ __global__ __launch_bounds__(256) void k_mailbox_allgather(MailboxView mv, int c
             *reinterpret_cast<d2 *>(out + 2 * i) = *reinterpret_cast<const d2 *>(src + 2 * i);
         if ((count & 1) && tid == 0) out[count - 1] = src[count - 1];
         if (tail_n > 0 && tid == 0) out[count] = tail_sum;
-        __threadfence_system();   // release: my stores are visible system-wide before the flag below
+        __threadfence_system();   // every storing wave: write back, wait for its own stores (vmcnt is per wave), before the barrier
         __syncthreads();
         if (tid == 0) {
             unsigned long long *flag = reinterpret_cast<unsigned long long *>(
                 mv.base[peer] + ((long)chan * kMaxRanks + mv.rank) * kP2pFlagStride);
-            __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            // the same tail as chunk_publish: release fence, its own wait (the compiler drops the one behind buffer_wbl2 when it
+            // can prove this wave has nothing outstanding -- harmless here, every wave has drained above, but not left to that),
+            // then the flag as a relaxed system-scope store
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(flag, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     }
     // ---- wait for the peer's contribution in MY mailbox, then copy it out ------------------------------------
