@@ -98,7 +98,9 @@ typedef struct cgx_config {
                                  fences; the two words of a double leave as one 16-byte write-through store, readers poll with
                                  relaxed 8-byte system-scope atomic loads); 0 = payload stores + release,
                                  flag words, polls + acquire.  Both forms are checked by cgx_p2p_selftest with their own device
-                                 code.  (Was reserved[0].) */
+                                 code.  The tagged form rests on an aligned 8-byte half of a 16-byte write-through store arriving
+                                 untorn at the peer, which no run on more than one GPU has shown yet: the launchers' `auto` uses
+                                 the flag form and this one on request only.  (Was reserved[0].) */
 } cgx_config;
 
 typedef struct cgx_result {
