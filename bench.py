@@ -230,6 +230,33 @@ def cpu_baseline(n, iters):
         out["all_cores"] = {"value": iters / ra["seconds_loop"], "unit": "iterations/s", "cores": cores, "kind": "port",
                             "sample": "same, %d row blocks on %d threads" % (cores, cores),
                             "gemv_GBs": 8.0 * n * n * iters / ra["seconds_loop"] / 1e9}
+    # context row: the GEMV of the loop (99 % of it, figures/gprof.png) through the BLAS family the reference linked -- the OpenBLAS
+    # that numpy / scipy bundle, held to ONE thread -- on the same matrix: what cblas_dgemv (cg.cc:101-102) itself does on this host
+    try:
+        import numpy as np
+        from scipy.linalg import blas
+        from threadpoolctl import threadpool_limits
+        A = O.generate_lap2d(n)
+        v = O.init_source_term(n)
+        reps = max(3, iters // 2)
+        with threadpool_limits(limits=1, user_api="blas"):
+            blas.dgemv(1.0, A.T, v, trans=1)
+            t0 = time.time()
+            for _ in range(reps):
+                y = blas.dgemv(1.0, A.T, v, trans=1)
+            dt = time.time() - t0
+        ver = ""
+        try:
+            from threadpoolctl import threadpool_info
+            ver = ", ".join(sorted({"%s %s" % (i.get("internal_api"), i.get("version")) for i in threadpool_info() if i.get("user_api") == "blas"}))
+        except Exception:                  # noqa: BLE001
+            pass
+        out["openblas_gemv_1thread"] = {"value": reps / dt, "unit": "GEMVs/s (one per iteration)", "cores": 1, "gemv_GBs": 8.0 * n * n * reps / dt / 1e9,
+                                        "sample": "%d x dgemv of the %d x %d matrix through scipy.linalg.blas (%s), one thread" % (reps, n, n, ver or "OpenBLAS"),
+                                        "checksum": float(np.sum(y))}
+        del A
+    except Exception as e:                 # noqa: BLE001 -- context only
+        out["openblas_gemv_1thread"] = {"skipped": str(e)[:120]}
     return out
 
 
