@@ -43,6 +43,8 @@ def test_bench_line_contract(gpu_pkg):
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] == 1 and cb["value"] > 0 and "sample" in cb
+    ob = cb["openblas_gemv_1thread"]            # context: the loop's GEMV through the BLAS family the reference linked, one thread
+    assert ob.get("skipped") or (ob["cores"] == 1 and ob["value"] > 0 and ob["gemv_GBs"] > 0)
     assert "error" not in d
     # roofline.traffic: by default counters of THIS box (two rocprofv3 --pmc child passes of the same workload), per launch
     if rf["traffic_source"].startswith("LIVE"):
