@@ -114,6 +114,53 @@ static cgx_status scrub_tagged_region(cgx_ctx *ctx)
     return CGX_OK;
 }
 
+// The LDS-resident solver (cgx_resident.hip) takes a problem when: one GPU (CGX_COMM_SELF), dense storage, n <= 2048, the
+// default K1 choice (gemv_variant 0; 40000 asks for it and fails if it cannot be had; any explicit per-launch shape, -1 or
+// CGX_RESIDENT=0 keep the per-launch path), and all of its workgroups are resident at once (they wait for each other).
+static cgx_status setup_resident(cgx_ctx *ctx, int variant)
+{
+    ctx->resident = false;
+    const bool forced = variant == 40000;
+    if (!forced && variant != 0) return CGX_OK;
+    const char *env = getenv("CGX_RESIDENT");
+    if (!forced && env && atoi(env) == 0) return CGX_OK;
+    auto no = [&](const char *why) {
+        return forced ? fail(ctx, CGX_ERR_UNSUPPORTED, std::string("gemv_variant 40000 (LDS-resident solver): ") + why) : CGX_OK;
+    };
+    if (ctx->cfg.comm_mode != CGX_COMM_SELF || ctx->banded) return no("one GPU (CGX_COMM_SELF) and dense storage only");
+    cgx::ResidentPlan pl{};
+    if (!cgx::plan_resident(ctx->n, ctx->cus, ctx->lds_per_cu, &pl)) return no("the matrix does not fit the LDS of the CUs (n <= 2048)");
+    int per_cu = 0;
+    if (cgx::prepare_cg_resident(pl, &per_cu) != hipSuccess) {
+        (void)hipGetLastError();
+        return no("the runtime refused the kernel's LDS request");
+    }
+    int limit = per_cu * ctx->cus;
+    if (ctx->resident_limit > 0) limit = ctx->resident_limit;
+    if (pl.grid > limit) return no("its workgroups would not all be resident at once");
+    const size_t need = (size_t)2 * pl.xslots * 2 * sizeof(unsigned long long);
+    if (need > ctx->res_xbuf_bytes) {
+        (void)hipFree(ctx->res_xbuf);
+        ctx->res_xbuf = nullptr;
+        ctx->res_xbuf_bytes = 0;
+        const size_t bytes = (size_t)2 * 2048 * 2 * sizeof(unsigned long long);   // the largest plan: 64 KiB
+        // ordinary device memory: the tagged words travel with agent-scope (sc1) stores and loads; fine-grained memory and
+        // system scope, as between GPUs, measured the same (profiles/r04_resident/)
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->res_xbuf), bytes));
+        ctx->res_xbuf_bytes = bytes;
+    }
+    if (!ctx->d_res_err) {
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_res_err), sizeof(int)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_res_err, 0, sizeof(int), ctx->stream));
+    }
+    // a freshly laid out exchange buffer holds zeros only (no tag is 0): what a reader finds in a position is then a zero or
+    // a tagged word of an earlier epoch of THIS geometry, never something another problem size left there
+    HIP_TRY(ctx, hipMemsetAsync(ctx->res_xbuf, 0, ctx->res_xbuf_bytes, ctx->stream));
+    ctx->rplan = pl;
+    ctx->resident = true;
+    return CGX_OK;
+}
+
 // Allocate the shards for an n x n problem (matrix contents are filled by the caller).
 cgx_status setup_problem(cgx_ctx *ctx, int n)
 {
@@ -160,8 +207,10 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
     const bool fused_p2p = ctx->cfg.comm_mode == CGX_COMM_P2P && !ctx->cfg.p2p_separate_exchange;
     ctx->chunked = (ctx->nranks > 1 && !ctx->banded) || fused_p2p;
     const bool allow_split = ctx->chunked && !ctx->banded && ctx->nranks > 1;
+    // (40000 = the LDS-resident solver, setup_resident below: set-up, verification and the probes still run the default K1)
+    const int k1_variant = variant == 40000 ? 0 : variant;
     auto plan_for = [&](int rows) {
-        return ctx->banded ? cgx::plan_dia(rows, variant) : cgx::plan_gemv(variant, rows, ctx->n, ctx->lda, allow_split);
+        return ctx->banded ? cgx::plan_dia(rows, k1_variant) : cgx::plan_gemv(k1_variant, rows, ctx->n, ctx->lda, allow_split);
     };
     int grid_max = 1;
     for (int q = 0; q < ctx->nranks; ++q) {
@@ -267,6 +316,7 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
         HIP_TRY(ctx, hipMemsetAsync(s.sc, 0, sizeof(Scalars), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(s.gathered, 0, (size_t)cgx::kMaxRanks * cgx::kSlots * sizeof(double), ctx->stream));
     }
+    CGX_TRY(setup_resident(ctx, variant));
     if (ctx->cfg.comm_mode == CGX_COMM_LOOPBACK) {
         std::vector<double *> gp(nlocal);
         std::vector<Scalars *> sp(nlocal);
@@ -393,6 +443,9 @@ cgx_status cgx_create(cgx_ctx **out, const cgx_config *cfg_in)
         ctx->err = std::string("device is ") + prop.gcnArchName + ", libcgx is built for gfx950 (MI355X) only";
         return bail(CGX_ERR_NO_DEVICE);
     }
+    ctx->cus = prop.multiProcessorCount;
+    ctx->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
+    ctx->res_timeout_ticks = (long long)(cfg.p2p_timeout_ms > 0 ? cfg.p2p_timeout_ms : 5000) * 100000LL;   // 100 MHz
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
         ctx->err = "hipStreamCreate failed";
         return bail(CGX_ERR_HIP);
@@ -482,6 +535,11 @@ cgx_status cgx_get_gemv_plan(const cgx_ctx *ctx, int local_shard, int out[CGX_GE
 {
     if (!ctx || !out || local_shard < 0 || local_shard >= (int)ctx->shards.size()) return CGX_ERR_BAD_ARG;
     const cgx::GemvPlan &pl = ctx->shards[(size_t)local_shard].plan;
+    if (ctx->resident) {   // variant 4: the loop runs as one persistent kernel on LDS-resident row groups (U = column steps of 512)
+        const int r[CGX_GEMV_PLAN_INTS] = {4, ctx->rplan.R, ctx->rplan.S, 4, 0, 1, ctx->rplan.grid, pl.ncols};
+        memcpy(out, r, sizeof r);
+        return CGX_OK;
+    }
     const int v[CGX_GEMV_PLAN_INTS] = {pl.variant, pl.R, pl.U, pl.waves, pl.light, pl.split, pl.grid, pl.ncols};
     memcpy(out, v, sizeof v);
     return CGX_OK;
@@ -658,6 +716,8 @@ cgx_status cgx_destroy(cgx_ctx *ctx)
         if (ctx->mailbox) (void)(ctx->mailbox_on_host ? hipHostFree(ctx->mailbox) : hipFree(ctx->mailbox));
         if (ctx->d_p2p_err) (void)hipFree(ctx->d_p2p_err);
     }
+    (void)hipFree(ctx->res_xbuf);
+    (void)hipFree(ctx->d_res_err);
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (auto e : ctx->upd_pool) (void)hipEventDestroy(e);
     for (auto e : ctx->steps_ev)

@@ -85,6 +85,17 @@ struct cgx_ctx {
                                  // run and every fused P2P update; else K1's own partials (one GPU; banded storage)
     int resident_limit = 0;      // > 0: test override of the co-residency bound of the fused P2P update (cgx_probe_set_resident_limit)
 
+    // LDS-resident solver (cgx_resident.hip): one GPU, dense, n <= 2048
+    int cus = 0;                             // compute units of the device
+    size_t lds_per_cu = 0;                   // LDS bytes a workgroup can be given
+    bool resident = false;                   // the current problem runs the loop as one persistent kernel
+    cgx::ResidentPlan rplan{};
+    unsigned long long *res_xbuf = nullptr;  // exchange buffer of the resident kernel's workgroups (tagged words)
+    size_t res_xbuf_bytes = 0;
+    unsigned long long res_epoch = 0;        // epochs handed out so far (monotonic over the life of the context)
+    int *d_res_err = nullptr;                // device word raised when a wait inside the resident kernel expired
+    long long res_timeout_ticks = 0;
+
     // loopback pointer tables (device)
     double **d_gathered_ptrs = nullptr;
     cgx::Scalars **d_scalar_ptrs = nullptr;

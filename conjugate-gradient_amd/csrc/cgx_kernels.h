@@ -243,6 +243,41 @@ hipError_t launch_chunk_exchange_selftest(int n, int rows, int row0, const doubl
 // its workgroups wait for each other inside the kernel.
 hipError_t update_xr_p2p_resident_limit(int device, bool tagged, int *workgroups);
 
+// ---- the LDS-resident solver for small dense problems (cgx_resident.hip) ----------------------------------------------
+// n <= 2048 on one GPU: the row groups of A live in the CUs' LDS for the whole launch, x / r / p are replicated in every
+// workgroup's registers, and the loop cg.cc:95-137 runs inside ONE persistent kernel whose workgroups exchange Ap as tagged
+// words (no grid barrier).  All workgroups wait for each other: the grid never exceeds the number of CUs.
+struct ResidentPlan {
+    int R;             // rows per workgroup: the power of two with R x min(CUs, 256) >= n (<= 8)
+    int S;             // column steps of 512
+    int rows_per_wg;   // = R
+    int grid;          // workgroups = ceil(n / R) <= CUs
+    int xslots;        // tagged doubles per parity of the exchange buffer (512 * S)
+    size_t lds_bytes;  // dynamic LDS of one workgroup
+};
+struct ResidentArgs {
+    const double *A;   // n x lda, row-major, pad columns zero
+    long lda;
+    int n, rows_per_wg, xslots;
+    double *x, *r, *p; // n doubles each: the state between launches (p is read only when k0 > 0)
+    Scalars *sc;       // rs[], done, k_final in the per-launch path's convention
+    unsigned long long *xbuf;   // device memory, 2 parities x xslots x 2 words, zero-filled when the problem is set
+    unsigned long long epoch0;  // the launch uses epochs epoch0 + 1 ... epoch0 + iters
+    int k0, iters;     // iterations k0 ... k0 + iters - 1 (stops at the break of cg.cc:120-121)
+    double tol;
+    long long timeout_ticks;    // bound of every wait, 100 MHz wall-clock ticks
+    int *err;          // device word raised when a wait expired
+    long long *prof;   // diagnostics (CGX_RESIDENT_PROFILE=1), else nullptr: workgroup 0 adds up shader-clock cycles per phase
+                       // [0] GEMV + row sums + publish, [1] wait for the watched word, [2] gather, [3] p.Ap, [4] update + r.r,
+                       // [5] watch rounds, [6] gather rounds, [7] iterations
+};
+// false: this problem does not fit (n > 2048, too few CUs, LDS per workgroup too small).
+bool plan_resident(int n, int cus, size_t lds_per_wg, ResidentPlan *out);
+// Once per plan, before the first launch: raises the kernel's dynamic-LDS limit; *workgroups_per_cu = what the runtime
+// keeps resident per CU (the caller checks grid <= that x CUs: the workgroups wait for each other).
+hipError_t prepare_cg_resident(const ResidentPlan &pl, int *workgroups_per_cu);
+hipError_t launch_cg_resident(const ResidentPlan &pl, const ResidentArgs &a, hipStream_t s);
+
 // Loopback "collective": copy local[kSlots] of every shard into gathered[] of every shard (<= 16 shards).
 hipError_t launch_loopback_gather(double *const *gathered_ptrs, const Scalars *const *scalar_ptrs, int nshards,
                                   hipStream_t s);

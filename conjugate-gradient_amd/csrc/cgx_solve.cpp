@@ -291,6 +291,67 @@ cgx_status read_flags_sync(cgx_ctx *ctx)
     return CGX_OK;
 }
 
+// The loop cg.cc:95-137 as launches of the LDS-resident persistent kernel (cgx_resident.hip): up to kResidentBatch
+// iterations per launch (a launch of a non-converging solve stays bounded), state (x, r, p, rs[], done, k_final) in HBM in
+// between.  The break of cg.cc:120-121 is taken inside the kernel, at the iteration the reference takes it.
+constexpr int kResidentBatch = 1 << 16;
+
+cgx_status resident_steps(cgx_ctx *ctx, int nsteps)
+{
+    Shard &s = ctx->shards[0];
+    int left = std::min(nsteps, ctx->max_iter - ctx->k);
+    // diagnostics: CGX_RESIDENT_PROFILE=1 prints where workgroup 0 spent its cycles (per steps call, on stderr)
+    DeviceScratch scratch;
+    long long *d_prof = nullptr;
+    if (getenv("CGX_RESIDENT_PROFILE")) {
+        HIP_TRY(ctx, scratch.alloc(&d_prof, 8 * sizeof(long long)));
+        HIP_TRY(ctx, hipMemsetAsync(d_prof, 0, 8 * sizeof(long long), ctx->stream));
+    }
+    while (left > 0 && !ctx->done) {
+        const int batch = std::min(left, kResidentBatch);
+        cgx::ResidentArgs a{};
+        a.A = s.A;
+        a.lda = ctx->lda;
+        a.n = ctx->n;
+        a.rows_per_wg = ctx->rplan.rows_per_wg;
+        a.xslots = ctx->rplan.xslots;
+        a.x = s.x;
+        a.r = s.rv.base;
+        a.p = s.p[1];
+        a.sc = s.sc;
+        a.xbuf = ctx->res_xbuf;
+        a.epoch0 = ctx->res_epoch;
+        a.k0 = ctx->k;
+        a.iters = batch;
+        a.tol = ctx->tol;
+        a.timeout_ticks = ctx->res_timeout_ticks;
+        a.err = ctx->d_res_err;
+        a.prof = d_prof;
+        HIP_TRY(ctx, cgx::launch_cg_resident(ctx->rplan, a, ctx->stream));
+        ctx->res_epoch += (unsigned long long)batch;
+        ctx->k += batch;
+        left -= batch;
+        int *flags = ctx->h_flags + 4;
+        flags[2] = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(flags, &s.sc->done, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipMemcpyAsync(flags + 2, ctx->d_res_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->done = flags[0] != 0;
+        ctx->k_final = flags[1];
+        if (flags[2])
+            return fail(ctx, CGX_ERR_HIP, "LDS-resident solver: a wait for another workgroup's Ap expired (the grid was not resident at once?)");
+    }
+    if (d_prof) {
+        long long h[8];
+        HIP_TRY(ctx, hipMemcpy(h, d_prof, sizeof h, hipMemcpyDeviceToHost));
+        const double it = h[7] > 0 ? (double)h[7] : 1.0;
+        fprintf(stderr, "cgx resident profile: n=%d iterations=%lld cycles/iteration: gemv+publish %.0f  watch %.0f  gather %.0f  p.Ap %.0f  "
+                        "update+r.r %.0f  | rounds/iteration: watch %.2f gather %.2f\n",
+                ctx->n, h[7], h[0] / it, h[1] / it, h[2] / it, h[3] / it, h[4] / it, h[5] / it, h[6] / it);
+    }
+    return CGX_OK;
+}
+
 }  // namespace cgxi
 
 extern "C" {
@@ -345,6 +406,12 @@ cgx_status cgx_solve_steps(cgx_ctx *ctx, int nsteps, int *done_out)
     const double t0 = wall_now();
     // K1 statistics describe the most recent steps call (bench.py: the timed region, not the warmup)
     reset_gemv_stats(ctx);
+    if (ctx->resident) {
+        CGX_TRY(resident_steps(ctx, nsteps));
+        ctx->t_loop += wall_now() - t0;
+        if (done_out) *done_out = ctx->done ? 1 : 0;
+        return CGX_OK;
+    }
     bool window_open = false;   // the start marker of THIS call is on the stream (a stop marker is only paired with that)
     if (ctx->cfg.profile_gemv && nsteps > 0 && !ctx->done) {
         for (auto &e : ctx->steps_ev)
@@ -393,7 +460,9 @@ cgx_status cgx_solve_end(cgx_ctx *ctx, double *x, cgx_result *res)
     hipStream_t st = ctx->stream;
     // The convergence test of the last enqueued iteration is normally done by the NEXT K1; when the loop
     // ran out there is none, so close it here (cg.cc:117-121,132).
-    for (auto &s : ctx->shards) HIP_TRY(ctx, cgx::launch_close_iteration(s.sc, s.rv, ctx->k, ctx->tol, st));
+    // (the LDS-resident kernel has made that test itself; with no iteration done the state is the per-launch path's)
+    if (!ctx->resident || ctx->k == 0)
+        for (auto &s : ctx->shards) HIP_TRY(ctx, cgx::launch_close_iteration(s.sc, s.rv, ctx->k, ctx->tol, st));
     CGX_TRY(read_flags_sync(ctx));
     const int k_exit = ctx->done ? ctx->k_final : ctx->k;
 

@@ -1,0 +1,277 @@
+"""The LDS-resident solver (csrc/cgx_resident.hip: the loop code/MPI/cg.cc:95-137 as ONE persistent kernel, n <= 2048 on one
+GPU) against the oracle and against the per-launch path.  All marked gpu.
+
+The rest of the GPU suite runs with CGX_RESIDENT=0 (tests/conftest.py), so that its small cases keep exercising K1 / K3;
+here the resident kernel is asked for explicitly (gemv_variant 40000) or chosen by the library's default (environment
+variable removed).
+
+Tolerances (fp64): fixed-iteration solves ||dx||/||x|| <= 1e-12 and residual rel. 1e-10 against the oracle (the same bars as
+tests/test_gpu_parity.py); converged solves sqrt(rsnew) < tol, ||Ax-b||/||b|| <= 1e-11, k within 15 % of the oracle's.
+"""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RESIDENT = 40000      # cgx_config.gemv_variant: ask for the resident kernel, fail if it cannot be had
+LAUNCHES = -1         # the per-launch path with its default K1 shape
+
+
+def rel(a, b):
+    return abs(a - b) / abs(b)
+
+
+def lap(pkg, n, variant, max_iter=None, tol=None):
+    s = pkg.CGSolver(gemv_variant=variant)
+    s.generate_lap2d_matrix(n)
+    if max_iter is not None:
+        s.set_max_iter(max_iter)
+    if tol is not None:
+        s.tolerance(tol)
+    s.init_source_term(1.0 / n)
+    return s
+
+
+SIZES = [3, 7, 64, 255, 256, 257, 511, 512, 513, 1000, 1024, 1025, 1448, 1536, 1537, 2047, 2048]
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_fixed_iteration_solve_matches_oracle(gpu_pkg, oracle, n):
+    iters = max(1, min(n // 6, 40))     # not yet converged: a residual at rounding level has no digits to compare
+    with lap(gpu_pkg, n, RESIDENT, iters, 0.0) as s:
+        plan = s.gemv_plan()
+        x = np.zeros(n)
+        r = s.solve(x)
+    xo, ro = oracle.solve_lap2d(n, iters, 0.0, 1)
+    assert plan["variant"] == 4 and plan["grid"] <= 256 and plan["R"] * plan["grid"] >= n, plan
+    assert r["iterations"] == ro["iterations"] == iters and not r["converged"]
+    assert np.linalg.norm(x - xo) <= 1e-12 * np.linalg.norm(xo)
+    assert rel(r["residual_prev"], ro["residual_prev"]) <= 1e-10
+    assert rel(r["x_norm"], ro["x_norm"]) <= 1e-12
+
+
+@pytest.mark.parametrize("n", [1, 7, 300, 1000, 1024, 2048])
+def test_converged_solve(gpu_pkg, oracle, n):
+    with lap(gpu_pkg, n, RESIDENT) as s:
+        x = np.zeros(n)
+        r = s.solve(x)
+    xo, ro = oracle.solve_lap2d(n, None, 1e-10, 1)
+    if n == 1:      # A = [4], b = [0]: the reference's own 0/0 (cg.cc:107 with rsold = 0); NaN on both sides, no break
+        assert r["iterations"] == ro["iterations"] == 1 and np.isnan(x[0]) and np.isnan(xo[0])
+        return
+    assert r["converged"] and ro["converged"]
+    assert r["residual_last"] < 1e-10 <= r["residual_prev"]           # the break of cg.cc:120-121, taken at the first such k
+    assert abs(r["iterations"] - ro["iterations"]) <= 0.15 * ro["iterations"] + 1
+    assert r["rel_residual"] <= 1e-11
+    assert np.linalg.norm(x - xo) <= 1e-9 * np.linalg.norm(xo)
+
+
+def test_same_results_as_the_per_launch_path(gpu_pkg):
+    """Two different summation orders of the same recurrence: agreement to rounding, the same k on a converging run."""
+    n = 1448
+    out = {}
+    for name, v in (("resident", RESIDENT), ("launches", LAUNCHES)):
+        with lap(gpu_pkg, n, v) as s:
+            assert (s.gemv_plan()["variant"] == 4) == (name == "resident")
+            x = np.zeros(n)
+            out[name] = (s.solve(x), x)
+    (ra, xa), (rb, xb) = out["resident"], out["launches"]
+    assert ra["converged"] and rb["converged"] and abs(ra["iterations"] - rb["iterations"]) <= 2
+    assert np.linalg.norm(xa - xb) <= 1e-9 * np.linalg.norm(xb)
+
+
+def test_break_semantics_and_resuming(gpu_pkg):
+    """The loop cut into launches of any length gives the same bits as one launch: the state that crosses a launch boundary
+    (x, r, p, rsold) is complete, and after the break nothing is updated any more (cg.cc:120-121)."""
+    n = 1000
+    runs = []
+    for pieces in ([400], [1, 1, 2, 3, 5, 8, 13, 21, 34, 55, 257], [7] * 60):
+        with lap(gpu_pkg, n, RESIDENT, max_iter=400, tol=1e-10) as s:
+            s.solve_begin(np.zeros(n))
+            for k in pieces:
+                s.solve_steps(k)
+            x = np.zeros(n)
+            runs.append((s.solve_end(x), x))
+    r0, x0 = runs[0]
+    assert r0["converged"] and r0["iterations"] < 400
+    for r, x in runs[1:]:
+        assert r["iterations"] == r0["iterations"] and r["converged"]
+        assert r["residual_prev"] == r0["residual_prev"] and r["residual_last"] == r0["residual_last"]
+        assert np.array_equal(x, x0)
+
+
+def test_fixed_iterations_in_pieces_are_bit_identical(gpu_pkg):
+    n = 2048
+    runs = []
+    for pieces in ([120], [1] * 5 + [115], [60, 60]):
+        with lap(gpu_pkg, n, RESIDENT, max_iter=120, tol=0.0) as s:
+            s.solve_begin(np.zeros(n))
+            for k in pieces:
+                s.solve_steps(k)
+            x = np.zeros(n)
+            runs.append((s.solve_end(x), x))
+    for r, x in runs[1:]:
+        assert r["iterations"] == 120 and r["residual_prev"] == runs[0][0]["residual_prev"]
+        assert np.array_equal(x, runs[0][1])
+
+
+def test_max_iter_zero_and_one(gpu_pkg, oracle):
+    n = 513
+    for iters in (0, 1):
+        with lap(gpu_pkg, n, RESIDENT, iters, 0.0) as s:
+            x = np.zeros(n)
+            r = s.solve(x)
+        xo, ro = oracle.solve_lap2d(n, iters, 0.0, 1)
+        assert r["iterations"] == ro["iterations"] == iters
+        assert rel(r["residual_prev"], ro["residual_prev"]) <= 1e-12
+        assert np.linalg.norm(x - xo) <= 1e-13 * max(np.linalg.norm(xo), 1e-300)
+
+
+@pytest.mark.parametrize("n", [777, 1536, 2048])
+def test_dense_hash_matrix(gpu_pkg, oracle, n):
+    """Every element of the matrix a different number (the generator leaves five non-zeros per row): a lane that read the
+    wrong LDS word would show."""
+    seed, it = 4242 + n, 30
+    diag = 1.03 * 2.0 * (n / 3.0) ** 0.5
+    with gpu_pkg.CGSolver(gemv_variant=RESIDENT) as s:
+        s.generate_lap2d_matrix(n)
+        s.probe_fill_matrix_hash(seed, symmetric=True, diag=diag)
+        s.set_max_iter(it)
+        s.tolerance(0.0)
+        s.init_source_term(1.0 / n)
+        x = np.zeros(n)
+        r = s.solve(x)
+    xo, ro = oracle.solve(oracle.hash_rows(n, 0, n, seed, True, diag), oracle.init_source_term(n), max_iter=it, tol=0.0)
+    assert r["iterations"] == ro["iterations"] == it
+    assert np.linalg.norm(x - xo) <= 1e-12 * np.linalg.norm(xo)
+    assert rel(r["residual_prev"], ro["residual_prev"]) <= 1e-10
+
+
+def test_caller_matrix_initial_guess_and_alpha_safeguard(gpu_pkg, oracle):
+    rng = np.random.default_rng(11)
+    n = 333
+    M = rng.standard_normal((n, n))
+    A = M @ M.T + n * np.eye(n)
+    b = rng.standard_normal(n)
+    x0 = rng.standard_normal(n)
+    with gpu_pkg.CGSolver(gemv_variant=RESIDENT) as s:
+        s.set_matrix_dense(A)
+        s.set_source_term(b)
+        s.set_max_iter(40)
+        s.tolerance(0.0)
+        x = x0.copy()
+        r = s.solve(x)
+    xo, ro = oracle.solve(A, b, x0, 40, 0.0, 1)
+    assert np.linalg.norm(x - xo) <= 1e-12 * np.linalg.norm(xo) and rel(r["residual_prev"], ro["residual_prev"]) <= 1e-10
+    # A = -I: p.Ap < rsold * NEARZERO in every iteration, the second operand of std::max (cg.cc:107)
+    n = 96
+    A = -np.eye(n)
+    with gpu_pkg.CGSolver(gemv_variant=RESIDENT) as s:
+        s.set_matrix_dense(A)
+        s.set_source_term(b[:n].copy())
+        s.set_max_iter(3)
+        x = np.zeros(n)
+        r = s.solve(x)
+    xo, ro = oracle.solve(A, b[:n].copy(), None, 3, 1e-10, 1)
+    assert r["iterations"] == ro["iterations"] == 3 and np.linalg.norm(x) > 1e40
+    assert np.linalg.norm(x - xo) <= 1e-12 * np.linalg.norm(xo)
+
+
+def test_context_reuse_across_sizes(gpu_pkg):
+    """One context, problems of changing size and repeated solves: the exchange buffer is laid out anew (zero-filled) for every
+    geometry and the epoch counter only grows, so no solve can read a tagged word of an earlier one."""
+    fresh = {}
+    for n in (2048, 1024, 600):
+        with lap(gpu_pkg, n, RESIDENT, 60, 0.0) as s:
+            x = np.zeros(n)
+            s.solve(x)
+            fresh[n] = x
+    with gpu_pkg.CGSolver(gemv_variant=RESIDENT) as s:
+        for n in (2048, 1024, 2048, 600, 2048, 1024):
+            s.generate_lap2d_matrix(n)
+            s.set_max_iter(60)
+            s.tolerance(0.0)
+            s.init_source_term(1.0 / n)
+            for _ in range(2):
+                x = np.zeros(n)
+                s.solve(x)
+                assert np.array_equal(x, fresh[n]), n
+
+
+def test_selection(gpu_pkg, monkeypatch):
+    """Default = resident where it fits; an explicit per-launch shape, -1, CGX_RESIDENT=0, a larger matrix, several row blocks or
+    banded storage keep the per-launch path; asking for it where it cannot be had is an error, not a silent fallback."""
+    monkeypatch.delenv("CGX_RESIDENT", raising=False)
+    with lap(gpu_pkg, 1024, 0) as s:
+        assert s.gemv_plan()["variant"] == 4
+    with lap(gpu_pkg, 2049, 0) as s:
+        assert s.gemv_plan()["variant"] == 1
+    with lap(gpu_pkg, 1024, 10421) as s:
+        assert s.gemv_plan()["variant"] == 1
+    with lap(gpu_pkg, 1024, LAUNCHES) as s:
+        assert s.gemv_plan()["variant"] == 1
+    monkeypatch.setenv("CGX_RESIDENT", "0")
+    with lap(gpu_pkg, 1024, 0) as s:
+        assert s.gemv_plan()["variant"] == 1
+    with lap(gpu_pkg, 1024, RESIDENT) as s:       # the explicit request is not overridden by the environment
+        assert s.gemv_plan()["variant"] == 4
+    monkeypatch.delenv("CGX_RESIDENT")
+    with pytest.raises(gpu_pkg.CgxError) as e:
+        lap(gpu_pkg, 2049, RESIDENT)
+    assert "does not fit" in str(e.value)
+    with gpu_pkg.CGSolver(comm_mode=gpu_pkg.COMM_LOOPBACK, nranks=2, gemv_variant=0) as s:
+        s.generate_lap2d_matrix(1024)
+        assert s.gemv_plan()["variant"] == 1
+    with gpu_pkg.CGSolver(comm_mode=gpu_pkg.COMM_LOOPBACK, nranks=2, gemv_variant=RESIDENT) as s:
+        with pytest.raises(gpu_pkg.CgxError):
+            s.generate_lap2d_matrix(1024)
+    with gpu_pkg.CGSolver(matrix_format=gpu_pkg.MATRIX_BANDED) as s:
+        s.generate_lap2d_matrix(1024)
+        assert s.gemv_plan()["variant"] == 3
+
+
+def test_grid_must_be_resident_at_once(gpu_pkg, monkeypatch):
+    """The workgroups wait for each other inside the kernel: when the device would not keep all of them resident the default
+    falls back to the per-launch path and the explicit request is refused."""
+    monkeypatch.delenv("CGX_RESIDENT", raising=False)
+    with gpu_pkg.CGSolver(gemv_variant=0) as s:
+        s._set_resident_limit(100)
+        s.generate_lap2d_matrix(1024)          # 256 workgroups
+        assert s.gemv_plan()["variant"] == 1
+        s.generate_lap2d_matrix(300)           # 150 workgroups of 2 rows
+        assert s.gemv_plan()["variant"] == 1
+        s.generate_lap2d_matrix(100)           # 100 workgroups
+        assert s.gemv_plan()["variant"] == 4
+    with gpu_pkg.CGSolver(gemv_variant=RESIDENT) as s:
+        s._set_resident_limit(100)
+        with pytest.raises(gpu_pkg.CgxError) as e:
+            s.generate_lap2d_matrix(1024)
+        assert "resident at once" in str(e.value)
+
+
+def test_cgsolver_cli_takes_the_resident_path_by_default(gpu_pkg, oracle, tmp_path):
+    """`cgsolver 1024 out` (code/MPI/cg_main.cc:13-69): same lines as with CGX_RESIDENT=0, to rounding."""
+    exe = os.path.join(ROOT, "conjugate-gradient_amd", "cgsolver")
+    outs = {}
+    for name, val in (("resident", None), ("launches", "0")):
+        env = dict(os.environ)
+        env.pop("CGX_RESIDENT", None)
+        if val is not None:
+            env["CGX_RESIDENT"] = val
+        out = tmp_path / (name + ".txt")
+        p = subprocess.run([exe, "1024", str(out), "--stats"], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        outs[name] = p.stdout + p.stderr
+    _, ro = oracle.solve_lap2d(1024, None, 1e-10, 1)
+    import re
+    ks = {}
+    for name, text in outs.items():
+        m = re.search(r"\[STEP (\d+)\]", text)
+        assert m, text
+        ks[name] = int(m.group(1))
+    assert abs(ks["resident"] - ro["iterations"]) <= 0.15 * ro["iterations"] + 1
+    assert abs(ks["resident"] - ks["launches"]) <= 2

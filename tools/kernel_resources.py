@@ -2,7 +2,7 @@
 """Print VGPR/SGPR/LDS/occupancy per kernel of csrc/cgx_kernels.hip (hipcc -Rpass-analysis)."""
 import os, re, subprocess, sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(root, "conjugate-gradient_amd", "csrc", "cgx_kernels.hip")
+src = os.path.join(root, "conjugate-gradient_amd", "csrc", os.environ.get("CGX_KERNEL_FILE", "cgx_kernels.hip"))
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-I/opt/rocm/include", "-c", src,
        "-o", "/tmp/_cgx_k.o", "-Rpass-analysis=kernel-resource-usage"]
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
