@@ -74,7 +74,14 @@ typedef struct cgx_config {
     int  rank;                /* CGX_COMM_RCCL: this process's shard; else 0                */
     int  nranks;              /* number of row blocks (the reference's psize)               */
     unsigned char unique_id[CGX_UNIQUE_ID_BYTES]; /* CGX_COMM_RCCL: from cgx_comm_unique_id */
-    int  gemv_variant;        /* 0 = library default; see DESIGN.md "K1 variants"           */
+    int  gemv_variant;        /* 0 = library default: the per-launch path (K1 + K3 per iteration) with the K1 shape chosen from the
+                                 block size -- or, for a dense matrix of n <= 2048 on one GPU (CGX_COMM_SELF), the LDS-resident
+                                 solver: the whole loop cg.cc:95-137 as ONE persistent kernel, every row group of A held in a
+                                 CU's LDS (csrc/cgx_resident.hip; 3-4 us per iteration instead of 7-12).
+                                 40000 = ask for the LDS-resident solver (CGX_ERR_UNSUPPORTED where it cannot be had);
+                                 -1 = the per-launch path with its default shape, also where the resident solver would fit
+                                 (as does CGX_RESIDENT=0 in the environment); v*10000 + R*100 + U*10 + d = an explicit
+                                 per-launch K1 shape, see DESIGN.md "K1 variants"              */
     int  lda_pad;             /* extra doubles added to the row pitch (-1 = library default)*/
     int  check_every;         /* iterations between host polls of the device `done` flag (0 = default) */
     int  profile_gemv;        /* n > 0 = bracket every n-th K1 launch with HIP events (at most 2048 per cgx_solve_steps call);
@@ -144,9 +151,11 @@ const char *cgx_status_string(cgx_status s);
 cgx_status  cgx_get_comm_info(cgx_ctx *ctx, int *comm_mode, int *ranks_wired, int *rank_seen, char *device_id);
 
 /* The K1 (GEMV, cg.cc:100-102) launch shape the library planned for local shard `local_shard` of the current problem,
- * for the benchmark record (which kernel ran): out = {variant (1 column-split, 2 LDS-staged p tiles, 3 banded), R rows per
- * workgroup (variant 2: per wave), U steps in flight, waves per workgroup, light (1 = the one-round form), split (column
- * pieces per row group, tied to the XCDs), grid (workgroups of one fused launch), ncols (columns swept)}. */
+ * for the benchmark record (which kernel ran): out = {variant (1 column-split, 2 LDS-staged p tiles, 3 banded, 4 = the loop
+ * runs in the LDS-resident persistent kernel), R rows per workgroup (variant 2: per wave), U steps in flight (variant 4:
+ * column steps of 512), waves per workgroup, light (1 = the one-round form), split (column pieces per row group, tied to the
+ * XCDs), grid (workgroups of one fused launch; variant 4: of the persistent kernel, all resident at once), ncols (columns
+ * swept)}. */
 #define CGX_GEMV_PLAN_INTS 8
 cgx_status  cgx_get_gemv_plan(const cgx_ctx *ctx, int local_shard, int out[CGX_GEMV_PLAN_INTS]);
 
