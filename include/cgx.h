@@ -250,7 +250,9 @@ cgx_status  cgx_probe_p2p_mailbox_to_host(cgx_ctx *ctx);
 cgx_status  cgx_probe_p2p_host_mailboxes(cgx_ctx *ctx, const char *prefix, int stage);
 /* Test hook for the co-residency guard of CGX_COMM_P2P's fused update kernel (its workgroups wait for each other inside the
  * kernel, so its grid must not exceed what the device keeps resident: occupancy x CUs, queried from the runtime when a
- * problem is set): workgroups > 0 replaces the queried bound for the problems set afterwards, 0 restores it. */
+ * problem is set): workgroups > 0 replaces the queried bound for the problems set afterwards, 0 restores it.  The same bound
+ * guards the LDS-resident solver (its workgroups wait for each other as well): with a bound below its grid the default falls
+ * back to the per-launch path and gemv_variant 40000 is refused. */
 cgx_status  cgx_probe_set_resident_limit(cgx_ctx *ctx, int workgroups);
 /* TEST ONLY: the epoch counter of mailbox channel `chan` (0 = plain segment all-gathers of a tagged-word context, 1 = the
  * iteration's exchange, 2 = DEBUG scalars).  set: move it FORWARD to `value` (the next exchange is value + 1) so that tests
