@@ -31,7 +31,7 @@ EXPORTS = [
     "cgx_probe_gemv", "cgx_probe_time_gemv", "cgx_probe_vector_ops", "cgx_probe_get_matrix_rows",
     "cgx_probe_get_source_term", "cgx_probe_set_fault_after", "cgx_probe_set_resident_limit",
     "cgx_probe_parse_matrix_market", "cgx_probe_p2p_mailbox_to_host", "cgx_probe_fill_matrix_hash",
-    "cgx_probe_set_p2p_epoch", "cgx_probe_get_p2p_epoch", "cgx_probe_p2p_host_mailboxes",
+    "cgx_probe_set_p2p_epoch", "cgx_probe_get_p2p_epoch", "cgx_probe_p2p_host_mailboxes", "cgx_probe_resident_test",
 ]
 
 
@@ -136,6 +136,7 @@ def lib():
         L.cgx_probe_fill_matrix_hash.argtypes = [vp, C.c_ulonglong, C.c_int, C.c_double]
         L.cgx_probe_p2p_host_mailboxes.argtypes = [vp, C.c_char_p, C.c_int]
         L.cgx_probe_set_p2p_epoch.argtypes = [vp, C.c_int, C.c_ulonglong]
+        L.cgx_probe_resident_test.argtypes = [vp, C.c_ulonglong, C.c_int]
         L.cgx_probe_get_p2p_epoch.argtypes = [vp, C.c_int, C.POINTER(C.c_ulonglong)]
         L.cgx_probe_parse_matrix_market.argtypes = [C.c_char_p, C.c_int, ip, ip, ip, ip, ip, ip, dp, C.c_long, C.c_char_p, C.c_int]
         for name in EXPORTS:
@@ -409,6 +410,10 @@ class CGSolver:
         v = C.c_ulonglong()
         self._check(lib().cgx_probe_get_p2p_epoch(self._h, int(chan), C.byref(v)))
         return v.value
+
+    def _resident_test(self, epoch=0, mute_workgroup=-1):
+        """Test hook of the LDS-resident solver: move its epoch counter forward / make one workgroup of the next launch skip a publish."""
+        self._check(lib().cgx_probe_resident_test(self._h, int(epoch), int(mute_workgroup)))
 
     def _set_resident_limit(self, workgroups):
         """Test hook: bound of co-resident workgroups the fused P2P update may assume (0 = ask the runtime)."""

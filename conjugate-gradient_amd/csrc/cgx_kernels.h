@@ -267,6 +267,7 @@ struct ResidentArgs {
     double tol;
     long long timeout_ticks;    // bound of every wait, 100 MHz wall-clock ticks
     int *err;          // device word raised when a wait expired
+    int mute_wg;       // test only (cgx_probe_resident_test): this workgroup leaves out the publish of the launch's first iteration; -1 = none
     long long *prof;   // diagnostics (CGX_RESIDENT_PROFILE=1), else nullptr: workgroup 0 adds up shader-clock cycles per phase
                        // [0] GEMV + row sums + publish, [1] wait for the watched word, [2] gather, [3] p.Ap, [4] update + r.r,
                        // [5] watch rounds, [6] gather rounds, [7] iterations

@@ -203,6 +203,18 @@ cgx_status cgx_probe_set_p2p_epoch(cgx_ctx *ctx, int chan, unsigned long long va
     return CGX_OK;
 }
 
+cgx_status cgx_probe_resident_test(cgx_ctx *ctx, unsigned long long epoch, int mute_workgroup)
+{
+    if (!ctx) return CGX_ERR_BAD_ARG;
+    if (ctx->in_solve) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_probe_resident_test inside begin/end");
+    if (epoch > 0) {
+        if (epoch < ctx->res_epoch) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_probe_resident_test: the epoch can only move forward");
+        ctx->res_epoch = epoch;
+    }
+    ctx->res_mute_wg = mute_workgroup;
+    return CGX_OK;
+}
+
 cgx_status cgx_probe_get_p2p_epoch(cgx_ctx *ctx, int chan, unsigned long long *value)
 {
     if (!ctx || !value || ctx->cfg.comm_mode != CGX_COMM_P2P || chan < 0 || chan >= cgx::kP2pChannels) return CGX_ERR_BAD_ARG;

@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
         const int myrow = wave_sum_rows<R>(acc, lane);               // acc[0] = this wave's part of row `myrow`
         if ((lane & (64 / R - 1)) == 0) red[wave * R + myrow] = acc[0];
         __syncthreads();
-        if (tid < my_rows) {
+        if (tid < my_rows && !(k == a.k0 && (int)blockIdx.x == a.mute_wg)) {   // (mute_wg: the test of the bounded waits)
             const double ap = (red[tid] + red[R + tid]) + (red[2 * R + tid] + red[3 * R + tid]);
             tagged_put(slot + 2 * (size_t)(row0 + tid), ap, tag);
         }

@@ -327,6 +327,8 @@ cgx_status resident_steps(cgx_ctx *ctx, int nsteps)
         a.timeout_ticks = ctx->res_timeout_ticks;
         a.err = ctx->d_res_err;
         a.prof = d_prof;
+        a.mute_wg = ctx->res_mute_wg;
+        ctx->res_mute_wg = -1;
         HIP_TRY(ctx, cgx::launch_cg_resident(ctx->rplan, a, ctx->stream));
         ctx->res_epoch += (unsigned long long)batch;
         ctx->k += batch;

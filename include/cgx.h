@@ -260,6 +260,12 @@ cgx_status  cgx_probe_set_resident_limit(cgx_ctx *ctx, int workgroups);
  * same call between two solves.  A smaller value is refused (flag words only grow). */
 cgx_status  cgx_probe_set_p2p_epoch(cgx_ctx *ctx, int chan, unsigned long long value);
 cgx_status  cgx_probe_get_p2p_epoch(cgx_ctx *ctx, int chan, unsigned long long *value);
+/* TEST ONLY, the LDS-resident solver (gemv_variant 0 / 40000, n <= 2048 on one GPU).  epoch > 0: move the epoch counter of
+ * its tagged-word exchange FORWARD to `epoch` (the next iteration uses epoch + 1), so that tests reach the wrap of the 32-bit
+ * tag without 4e9 iterations; a smaller value is refused.  mute_workgroup >= 0: that workgroup of the NEXT launch leaves out the
+ * publish of its first iteration, so that every wait for it expires (the bounded-wait path: cgx_solve_steps then returns
+ * CGX_ERR_HIP after p2p_timeout_ms); -1 = none.  The mute disarms itself after one launch. */
+cgx_status  cgx_probe_resident_test(cgx_ctx *ctx, unsigned long long epoch, int mute_workgroup);
 /* Copy the device-resident source term of local shard `local_shard` (n doubles, what cgx_init_source_term /
  * cgx_set_source_term left in HBM) back to the host: the bit-exact check of cg.cc:230-231. */
 cgx_status  cgx_probe_get_source_term(cgx_ctx *ctx, int local_shard, double *b_out);

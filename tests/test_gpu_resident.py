@@ -275,3 +275,52 @@ def test_cgsolver_cli_takes_the_resident_path_by_default(gpu_pkg, oracle, tmp_pa
         ks[name] = int(m.group(1))
     assert abs(ks["resident"] - ro["iterations"]) <= 0.15 * ro["iterations"] + 1
     assert abs(ks["resident"] - ks["launches"]) <= 2
+
+
+def test_epoch_wrap_of_the_tag(gpu_pkg):
+    """The 32-bit tag of the exchange is 1 + epoch mod (2^32 - 1): solves that run across the wrap of the tag, of the epoch's
+    low 32 bits and of twice the period (cgx_probe_resident_test moves the counter there) give the bits of a fresh context."""
+    n, iters = 1448, 80
+    with lap(gpu_pkg, n, RESIDENT, iters, 0.0) as s:
+        x0 = np.zeros(n)
+        r0 = s.solve(x0)
+    for start in (2**32 - 1 - 30, 2**32 - 30, 2 * (2**32 - 1) - 41, 2**40):
+        with lap(gpu_pkg, n, RESIDENT, iters, 0.0) as s:
+            x = np.zeros(n)
+            s.solve(x)                                   # leaves tagged words of small epochs in the buffer
+            s._resident_test(epoch=start)
+            for _ in range(2):                           # the first crosses the boundary, the second starts behind it
+                x = np.zeros(n)
+                r = s.solve(x)
+                assert r["iterations"] == iters and r["residual_prev"] == r0["residual_prev"], start
+                assert np.array_equal(x, x0), start
+            with pytest.raises(gpu_pkg.CgxError):
+                s._resident_test(epoch=start - 1)        # the counter only moves forward
+
+
+def test_a_wait_that_expires_is_reported(gpu_pkg):
+    """Every wait inside the kernel is bounded: a workgroup that never publishes (test hook) makes the waits for it expire after
+    p2p_timeout_ms; the call returns an error instead of hanging, and the context solves again afterwards."""
+    import time
+    n = 1024
+    x_good = None
+    for mute in (0, 37, 255):
+        with gpu_pkg.CGSolver(gemv_variant=RESIDENT, p2p_timeout_ms=200) as s:
+            s.generate_lap2d_matrix(n)
+            s.set_max_iter(50)
+            s.tolerance(0.0)
+            s.init_source_term(1.0 / n)
+            x_good = np.zeros(n)
+            s.solve(x_good)
+            s._resident_test(mute_workgroup=mute)
+            t0 = time.perf_counter()
+            with pytest.raises(gpu_pkg.CgxError) as e:
+                s.solve(np.zeros(n))
+            assert "expired" in str(e.value) and time.perf_counter() - t0 < 5.0
+            # the error word is sticky for this context (like the P2P transport's): a new context is the way on
+            with pytest.raises(gpu_pkg.CgxError):
+                s.solve(np.zeros(n))
+    with lap(gpu_pkg, n, RESIDENT, 50, 0.0) as s:
+        x = np.zeros(n)
+        s.solve(x)
+    assert np.array_equal(x, x_good)
