@@ -3,7 +3,9 @@
 #include "cgx_internal.h"
 
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <fcntl.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <cctype>
@@ -156,6 +158,21 @@ static cgx_status setup_resident(cgx_ctx *ctx, int variant)
     // a freshly laid out exchange buffer holds zeros only (no tag is 0): what a reader finds in a position is then a zero or
     // a tagged word of an earlier epoch of THIS geometry, never something another problem size left there
     HIP_TRY(ctx, hipMemsetAsync(ctx->res_xbuf, 0, ctx->res_xbuf_bytes, ctx->stream));
+    if (ctx->res_lock_fd < 0 && !getenv("CGX_RESIDENT_NOLOCK")) {   // (the variable: diagnostics, to show what the lock is for)
+        // One resident grid at a time per device, across contexts and processes: its workgroups wait for each other, and two
+        // such grids dispatched at the same moment can each be given half of the CUs (neither fits a second workgroup beside
+        // its own on a CU at n = 2048) and then wait for workgroups that can never be placed, until the bounded waits expire.
+        // An advisory lock on a file named after the device's PCI bus id serialises them (held from launch to the
+        // synchronisation in resident_steps; released by the kernel when a process dies).  Best effort: where the file cannot
+        // be opened the launches go unserialised, as safe as before.
+        char bus[64] = "unknown";
+        (void)hipDeviceGetPCIBusId(bus, sizeof bus, ctx->device);
+        std::string name = std::string("/tmp/cgx_resident_") + bus + ".lock";
+        for (char &c : name)
+            if (c == ':') c = '_';
+        ctx->res_lock_fd = open(name.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
+        if (ctx->res_lock_fd >= 0) (void)fchmod(ctx->res_lock_fd, 0666);   // other users of the box share the device too
+    }
     ctx->rplan = pl;
     ctx->resident = true;
     return CGX_OK;
@@ -718,6 +735,7 @@ cgx_status cgx_destroy(cgx_ctx *ctx)
     }
     (void)hipFree(ctx->res_xbuf);
     (void)hipFree(ctx->d_res_err);
+    if (ctx->res_lock_fd >= 0) close(ctx->res_lock_fd);
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (auto e : ctx->upd_pool) (void)hipEventDestroy(e);
     for (auto e : ctx->steps_ev)

@@ -95,6 +95,7 @@ struct cgx_ctx {
     unsigned long long res_epoch = 0;        // epochs handed out so far (monotonic over the life of the context)
     int *d_res_err = nullptr;                // device word raised when a wait inside the resident kernel expired
     long long res_timeout_ticks = 0;
+    int res_lock_fd = -1;                    // advisory lock file of the device: one resident grid at a time (see resident_steps)
     int res_mute_wg = -1;                    // test only (cgx_probe_resident_test): workgroup that skips its first publish, next launch
 
     // loopback pointer tables (device)

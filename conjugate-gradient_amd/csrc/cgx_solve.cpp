@@ -14,6 +14,8 @@
 //     over all n rows in one fixed order (bit-identical everywhere) and forms p = r + beta p inside the next K1.
 #include "cgx_internal.h"
 
+#include <sys/file.h>
+
 #include <algorithm>
 #include <cctype>
 #include <chrono>
@@ -329,6 +331,12 @@ cgx_status resident_steps(cgx_ctx *ctx, int nsteps)
         a.prof = d_prof;
         a.mute_wg = ctx->res_mute_wg;
         ctx->res_mute_wg = -1;
+        // one resident grid at a time on this device (setup_resident): held until the kernel has finished
+        struct DeviceLock {
+            int fd;
+            explicit DeviceLock(int f) : fd(f) { if (fd >= 0 && flock(fd, LOCK_EX) != 0) fd = -1; }
+            ~DeviceLock() { if (fd >= 0) (void)flock(fd, LOCK_UN); }
+        } lock(ctx->res_lock_fd);
         HIP_TRY(ctx, cgx::launch_cg_resident(ctx->rplan, a, ctx->stream));
         ctx->res_epoch += (unsigned long long)batch;
         ctx->k += batch;

@@ -324,3 +324,59 @@ def test_a_wait_that_expires_is_reported(gpu_pkg):
         x = np.zeros(n)
         s.solve(x)
     assert np.array_equal(x, x_good)
+
+
+_WORKER = r"""
+import sys, hashlib
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import __graft_entry__ as g
+pkg = g.load_package()
+n, reps = int(sys.argv[2]), int(sys.argv[3])
+h = hashlib.sha256()
+with pkg.CGSolver(gemv_variant=40000, p2p_timeout_ms=3000) as s:
+    s.generate_lap2d_matrix(n); s.set_max_iter(150); s.tolerance(0.0); s.init_source_term(1.0 / n)
+    for _ in range(reps):
+        x = np.zeros(n); s.solve(x); h.update(x.tobytes())
+print("DIGEST", h.hexdigest())
+"""
+
+
+def test_two_processes_and_two_threads_at_once(gpu_pkg):
+    """A resident grid of n = 2048 takes the LDS of every CU; two of them dispatched at the same moment could each be given
+    half of the CUs and wait for the rest for ever (until the bounded waits expire).  The per-device advisory lock lets one
+    run at a time: concurrent solves from two processes, and from two threads of one process, all finish with the same bits."""
+    import threading
+    n, reps = 2048, 60
+    procs = [subprocess.Popen([sys.executable, "-c", _WORKER, ROOT, str(n), str(reps)], stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for _ in range(2)]
+    outs = [p.communicate(timeout=600) for p in procs]
+    digests = []
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, so + se
+        digests.append([l for l in so.splitlines() if l.startswith("DIGEST")][0])
+    assert digests[0] == digests[1]
+
+    results, errors = [None, None], []
+
+    def work(i):
+        try:
+            with gpu_pkg.CGSolver(gemv_variant=RESIDENT, p2p_timeout_ms=3000) as s:
+                s.generate_lap2d_matrix(n)
+                s.set_max_iter(150)
+                s.tolerance(0.0)
+                s.init_source_term(1.0 / n)
+                for _ in range(reps):
+                    x = np.zeros(n)
+                    s.solve(x)
+                results[i] = x
+        except Exception as e:      # noqa: BLE001
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    assert np.array_equal(results[0], results[1])
