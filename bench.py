@@ -88,6 +88,9 @@ def parse_args():
                          "different number -- roofline.dense_random; ~K more iterations)")
     # tests only (tests/test_gpu_bench.py): "<transport>:<stage>" or "extra:cpu baseline" never comes back.  An explicit
     # argument, not an environment variable: nothing in a user's environment changes what the benchmark does.
+    ap.add_argument("--no-reference-sizes", action="store_true",
+                    help="skip the extra `reference_sizes` (one GPU, after the measurement: iterations/s at the reference's own "
+                         "small sizes N = 1024 and 2048, LDS-resident kernel beside the per-launch path; ~1 s)")
     ap.add_argument("--test-hang", default="", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -128,7 +131,7 @@ def live_pmc_traffic(args, n):
         try:
             cmd = [exe, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable,
                    os.path.abspath(__file__), "--steps", "20", "--warmup", "5", "--matrix-size", str(n), "--variant", str(args.variant),
-                   "--lda-pad", str(args.lda_pad), "--no-cpu-baseline", "--no-solve-window", "--no-live-pmc", "--no-profile-gemv"]
+                   "--lda-pad", str(args.lda_pad), "--no-cpu-baseline", "--no-solve-window", "--no-live-pmc", "--no-profile-gemv", "--no-reference-sizes"]
             env = {k: v for k, v in os.environ.items()           # the child is a plain one-GPU run, never a rank of somebody's job
                    if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR",
                                 "MASTER_PORT", "TORCHELASTIC_RUN_ID")}
@@ -258,6 +261,36 @@ def cpu_baseline(n, iters):
     except Exception as e:                 # noqa: BLE001 -- context only
         out["openblas_gemv_1thread"] = {"skipped": str(e)[:120]}
     return out
+
+
+def reference_sizes(pkg, torch):
+    """The reference's own experiment sizes (code/MPI/cg.run:15-44: N = 1024, 2048 ... to convergence or 200 iterations) on this
+    GPU: iterations/s of the loop with the library's default (the LDS-resident persistent kernel) and with
+    the per-launch path (K1 + K3 per iteration), tol = 0, 2000 timed iterations after 200, best of 3.  Not the headline metric."""
+    import numpy as np
+    rows = []
+    for n in (1024, 2048):
+        row = {"n": n}
+        for name, variant in (("default", 0), ("per_launch", -1)):
+            with pkg.CGSolver(gemv_variant=variant) as s:
+                s.generate_lap2d_matrix(n)
+                s.set_max_iter(10 ** 8)
+                s.tolerance(0.0)
+                s.init_source_term(1.0 / n)
+                plan = s.gemv_plan()
+                s.solve_begin(np.zeros(n))
+                s.solve_steps(200)
+                best = float("inf")
+                for _ in range(3):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    s.solve_steps(2000)
+                    best = min(best, (time.perf_counter() - t0) / 2000)
+                s.solve_end()
+            row[name] = {"iterations_per_s": 1.0 / best, "us_per_iteration": best * 1e6,
+                         "kernel": "k_cg_resident (one persistent kernel, A in LDS)" if plan["variant"] == 4 else "K1 + K3 per iteration"}
+        rows.append(row)
+    return rows
 
 
 def problem_size(args, world):
@@ -810,6 +843,12 @@ class Bench:
                                           "WRITE_SIZE x 1024 exact; traffic_committed = the row of %s for the same K1 plan" % (note, TRAFFIC_FILE))
             else:
                 roof["traffic_live_note"] = note
+        if world == 1 and transport == "self" and not args.no_reference_sizes:
+            self.state["stage"] = "reference sizes"
+            try:
+                line["reference_sizes"] = reference_sizes(pkg, self.torch)
+            except Exception as e:                 # noqa: BLE001 -- an extra must never cost the line
+                line["reference_sizes"] = {"error": str(e)[:200]}
         if not args.no_cpu_baseline:
             # rank 0 only, after the timed region and outside every bracket; the other ranks wait at the teardown barrier
             self.state["stage"] = "cpu baseline"
