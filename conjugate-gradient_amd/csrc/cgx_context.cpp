@@ -116,7 +116,8 @@ static cgx_status scrub_tagged_region(cgx_ctx *ctx)
     return CGX_OK;
 }
 
-// The LDS-resident solver (cgx_resident.hip) takes a problem when: one GPU (CGX_COMM_SELF), dense storage, n <= 2048, the
+// The LDS-resident solver (cgx_resident.hip) takes a problem when: one GPU (CGX_COMM_SELF), dense storage, n <= 4096 (up to
+// 2048 all rows in LDS; above, 16 rows per workgroup in LDS + registers + a streamed rest), the
 // default K1 choice (gemv_variant 0; 40000 asks for it and fails if it cannot be had; any explicit per-launch shape, -1 or
 // CGX_RESIDENT=0 keep the per-launch path), and all of its workgroups are resident at once (they wait for each other).
 static cgx_status setup_resident(cgx_ctx *ctx, int variant)
@@ -131,7 +132,7 @@ static cgx_status setup_resident(cgx_ctx *ctx, int variant)
     };
     if (ctx->cfg.comm_mode != CGX_COMM_SELF || ctx->banded) return no("one GPU (CGX_COMM_SELF) and dense storage only");
     cgx::ResidentPlan pl{};
-    if (!cgx::plan_resident(ctx->n, ctx->cus, ctx->lds_per_cu, &pl)) return no("the matrix does not fit the LDS of the CUs (n <= 2048)");
+    if (!cgx::plan_resident(ctx->n, ctx->cus, ctx->lds_per_cu, &pl)) return no("the matrix does not fit the LDS and registers of the CUs (n <= 4096 on 256 CUs)");
     int per_cu = 0;
     if (cgx::prepare_cg_resident(pl, &per_cu) != hipSuccess) {
         (void)hipGetLastError();
@@ -145,7 +146,7 @@ static cgx_status setup_resident(cgx_ctx *ctx, int variant)
         (void)hipFree(ctx->res_xbuf);
         ctx->res_xbuf = nullptr;
         ctx->res_xbuf_bytes = 0;
-        const size_t bytes = (size_t)2 * 2048 * 2 * sizeof(unsigned long long);   // the largest plan: 64 KiB
+        const size_t bytes = (size_t)2 * 4096 * 2 * sizeof(unsigned long long);   // the largest plan: 128 KiB
         // ordinary device memory: the tagged words travel with agent-scope (sc1) stores and loads; fine-grained memory and
         // system scope, as between GPUs, measured the same (profiles/r04_resident/)
         HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->res_xbuf), bytes));
@@ -553,7 +554,8 @@ cgx_status cgx_get_gemv_plan(const cgx_ctx *ctx, int local_shard, int out[CGX_GE
     if (!ctx || !out || local_shard < 0 || local_shard >= (int)ctx->shards.size()) return CGX_ERR_BAD_ARG;
     const cgx::GemvPlan &pl = ctx->shards[(size_t)local_shard].plan;
     if (ctx->resident) {   // variant 4: the loop runs as one persistent kernel on LDS-resident row groups (U = column steps of 512)
-        const int r[CGX_GEMV_PLAN_INTS] = {4, ctx->rplan.R, ctx->rplan.S, 4, 0, 1, ctx->rplan.grid, pl.ncols};
+        // (light = rows of a workgroup held in registers: 0 up to n = 2048, where all of them are in LDS)
+        const int r[CGX_GEMV_PLAN_INTS] = {4, ctx->rplan.R, ctx->rplan.S, 4, ctx->rplan.RG, 1, ctx->rplan.grid, pl.ncols};
         memcpy(out, r, sizeof r);
         return CGX_OK;
     }

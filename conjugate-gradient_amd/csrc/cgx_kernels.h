@@ -254,6 +254,8 @@ struct ResidentPlan {
     int grid;          // workgroups = ceil(n / R) <= CUs
     int xslots;        // tagged doubles per parity of the exchange buffer (512 * S)
     size_t lds_bytes;  // dynamic LDS of one workgroup
+    int hybrid;        // 1 = 2048 < n <= 4096 (k_cg_hybrid): R = 16 rows per workgroup, of which RL in LDS, RG in registers and
+    int RL, RG;        //     R - RL - RG streamed from memory every iteration; 0: all R rows in LDS (RL = R, RG = 0)
 };
 struct ResidentArgs {
     const double *A;   // n x lda, row-major, pad columns zero
@@ -272,7 +274,7 @@ struct ResidentArgs {
                        // [0] GEMV + row sums + publish, [1] wait for the watched word, [2] gather, [3] p.Ap, [4] update + r.r,
                        // [5] watch rounds, [6] gather rounds, [7] iterations
 };
-// false: this problem does not fit (n > 2048, too few CUs, LDS per workgroup too small).
+// false: this problem does not fit (n > 4096, too few CUs, LDS per workgroup too small).
 bool plan_resident(int n, int cus, size_t lds_per_wg, ResidentPlan *out);
 // Once per plan, before the first launch: raises the kernel's dynamic-LDS limit; *workgroups_per_cu = what the runtime
 // keeps resident per CU (the caller checks grid <= that x CUs: the workgroups wait for each other).

@@ -70,6 +70,25 @@ __device__ __forceinline__ void tagged_wait(u4 (&w)[2 * S])
     if constexpr (S == 4)
         asm volatile("s_waitcnt vmcnt(0)"
                      : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7])::"memory");
+    if constexpr (S > 4) {   // (an asm statement takes at most 30 operands)
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7])::"memory");
+        if constexpr (S == 5) asm volatile("" : "+v"(w[8]), "+v"(w[9])::"memory");
+        if constexpr (S == 6) asm volatile("" : "+v"(w[8]), "+v"(w[9]), "+v"(w[10]), "+v"(w[11])::"memory");
+        if constexpr (S == 7) asm volatile("" : "+v"(w[8]), "+v"(w[9]), "+v"(w[10]), "+v"(w[11]), "+v"(w[12]), "+v"(w[13])::"memory");
+        if constexpr (S == 8)
+            asm volatile("" : "+v"(w[8]), "+v"(w[9]), "+v"(w[10]), "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15])::"memory");
+    }
+}
+
+// wait for the N 16-byte loads of a batch of streamed rows (the registers are operands, as in tagged_wait)
+template <int N>
+__device__ __forceinline__ void stream_wait(d2 *v)
+{
+    static_assert(N >= 1 && N <= 16, "a batch of streamed rows is at most 16 loads");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i])::"memory");
 }
 
 __device__ __forceinline__ double tagged_value(const u4 &w)
@@ -313,6 +332,310 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// 2048 < n <= 4096: the matrix (up to 128 MiB) no longer fits the LDS alone -- but a CU also has a 512 KB register file, and a
+// workgroup of 256 threads at one per CU may use all of it.  Same kernel structure, R = 16 rows per workgroup, kept in three
+// places: RL rows in LDS (as above), RG rows in REGISTERS (thread t holds its own 2 S columns of each: 4 S VGPRs per row, loaded
+// once per launch), and the remaining RS rows streamed from memory every iteration (non-temporal 16-byte loads, two rows per
+// batch, the first batch in flight while the LDS and register rows are multiplied).  S = 5: 7 + 9 + 0 (all resident, n <= 2560);
+// S = 6: 6 + 10 + 0 (all resident, n <= 3072); S = 7: 5 + 6 + 5; S = 8: 4 + 6 + 6 (n = 4096: 48 of 128 MiB re-read per iteration).
+// x is not replicated here: a workgroup keeps x for its own 16 rows only (nobody else needs it), r and p stay replicated.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int kHybR = 16;
+constexpr int hyb_rl(int S) { return (150 * 1024) / (S * 512 * 8) < kHybR ? (150 * 1024) / (S * 512 * 8) : kHybR; }
+// rows in registers: what the 512 registers of a thread hold beside r, p, the row sums, a batch of streamed rows and the
+// gather's words without a byte of scratch (hipcc 7.2: 364 / 451 / 481 / 501 registers at S = 5 / 6 / 7 / 8)
+constexpr int hyb_rg(int S) { return S == 5 ? 9 : S == 6 ? 10 : 6; }
+#define HYB_SB 2
+
+template <int S>
+__global__ __launch_bounds__(kResThreads, 1) void k_cg_hybrid(ResidentArgs a)
+{
+    constexpr int R = kHybR, RL = hyb_rl(S), RG = hyb_rg(S), RS = R - RL - RG, SB = HYB_SB;
+    extern __shared__ double lds_all[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = a.n;
+    constexpr int pitch = S * 512;
+    double *lds_A = lds_all;                          // RL x pitch
+    constexpr int kScratch = 4 * R + 8;
+    double *lds_red = lds_all + (size_t)RL * pitch;   // two sets of per-iteration scratch
+    double *lds_sum = lds_red + 2 * kScratch;         // 4 doubles for block_sum (set-up only)
+    double *lds_fail = lds_sum + 4;                   // one word: a wait of this workgroup expired
+    const int row0 = blockIdx.x * R;
+    const int my_rows = min(R, n - row0);             // >= 1 by construction of the grid
+
+    if (tid == 0) *reinterpret_cast<volatile int *>(lds_fail) = 0;
+    if (__syncthreads_or(__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return;
+
+    // a row of the block as this thread sees it: its 2 S columns; rows behind the last one are read as row n-1 (never published),
+    // columns behind the pitch as zero (columns n .. lda are zero in the block already)
+    auto row_ptr = [&](int i) { return a.A + (size_t)min(row0 + i, n - 1) * a.lda; };
+    auto a_load = [&](const double *row, int s) {
+        const int c = 512 * s + 2 * tid;
+        d2 v = {0.0, 0.0};
+        if (c < a.lda) v = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(row + c));
+        return v;
+    };
+
+    // The streamed rows are loaded with ONE 32-bit byte offset per column step (shared by all rows) on a workgroup-uniform row
+    // base in SGPRs: left to the compiler, the RS x S 64-bit addresses are hoisted out of the iteration loop and held in
+    // VGPRs (seen as 900 bytes of scratch per lane).  A column step that reaches behind the pitch reads the row's last pair of
+    // pad columns instead -- zero in the block by construction, and multiplied by p = 0 there.
+    unsigned soff[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const long c = 512 * s + 2 * tid;
+        soff[s] = (unsigned)(8 * (c < a.lda - 2 ? c : a.lda - 2));
+    }
+    auto stream_issue = [&](int i, int s) {
+        const double *row = row_ptr(i);
+        d2 v;
+        asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(v) : "v"(soff[s]), "s"(row) : "memory");
+        return v;
+    };
+
+    // ---- rows 0 .. RL-1 -> LDS, rows RL .. RL+RG-1 -> registers, once per launch
+    for (int i = 0; i < RL; ++i) {
+        const double *row = row_ptr(i);
+#pragma unroll
+        for (int s = 0; s < S; ++s) *reinterpret_cast<d2 *>(lds_A + (size_t)i * pitch + 512 * s + 2 * tid) = a_load(row, s);
+    }
+    d2 areg[RG > 0 ? RG : 1][S];
+#pragma unroll
+    for (int i = 0; i < RG; ++i) {
+        const double *row = row_ptr(RL + i);
+#pragma unroll
+        for (int s = 0; s < S; ++s) areg[i][s] = a_load(row, s);
+    }
+
+    // ---- state: r, p for this thread's columns (replicated in every workgroup); x for the workgroup's own rows only
+    d2 r[S], p[S];
+    unsigned okmask = 0;                                              // bit 2 s / 2 s + 1: column 512 s + 2 tid / + 1 is below n
+    d2 xo = {0.0, 0.0};
+    int sx = -1;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int c = 512 * s + 2 * tid;
+        const bool ok0 = c < n, ok1 = c + 1 < n;
+        okmask |= (ok0 ? 1u : 0u) << (2 * s) | (ok1 ? 1u : 0u) << (2 * s + 1);
+        r[s].x = ok0 ? a.r[c] : 0.0;
+        r[s].y = ok1 ? a.r[c + 1] : 0.0;
+        if (a.k0 > 0) {
+            p[s].x = ok0 ? a.p[c] : 0.0;
+            p[s].y = ok1 ? a.p[c + 1] : 0.0;
+        } else {
+            p[s] = r[s];                                              // p = r, cg.cc:85
+        }
+        if (c >= row0 && c < row0 + my_rows) {                        // at most one s: the workgroup's rows span 16 columns
+            sx = s;
+            xo.x = a.x[c];
+            if (c + 1 < row0 + my_rows) xo.y = a.x[c + 1];
+        }
+    }
+    double rsold, rs_prev;
+    if (a.k0 > 0) {
+        rsold = a.sc->rs[a.k0 & 1];
+        rs_prev = a.sc->rs[(a.k0 + 1) & 1];
+    } else {
+        double v = 0.0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) v += r[s].x * p[s].x + r[s].y * p[s].y;   // rsold = r.p, cg.cc:91-92
+        rsold = block_sum<4>(v, lds_sum);
+        rs_prev = rsold;
+    }
+    __syncthreads();   // the LDS rows are in place
+
+    int k = a.k0, stop = 0;
+    const int k_end = a.k0 + a.iters;
+    unsigned long long epoch = a.epoch0;
+    for (; k < k_end; ++k) {
+        ++epoch;
+        const unsigned tag = p2p_tag(epoch);
+        unsigned long long *slot = a.xbuf + (size_t)(epoch & 1) * (2 * a.xslots);
+        double *red = lds_red + (k & 1) * kScratch;     // [4 waves][R] row sums | [4] p.Ap | [4] r.r
+        const bool prof = a.prof != nullptr && blockIdx.x == 0 && tid == 0;
+        long long tp[6] = {0, 0, 0, 0, 0, 0};
+        int watch_rounds = 0, gather_rounds = 0;
+        if (prof) tp[0] = clock64();
+
+        // Ap_sub = A_sub p (cblas_dgemv, cg.cc:100-102): the thread's columns of every row, ascending
+        double acc[R];
+#pragma unroll
+        for (int i = 0; i < R; ++i) acc[i] = 0.0;
+        d2 sb[RS > 0 ? SB : 1][S];
+        if constexpr (RS > 0) {                                       // first batch of streamed rows: in flight during the rest
+#pragma unroll
+            for (int j = 0; j < SB; ++j)
+#pragma unroll
+                for (int s = 0; s < S; ++s) sb[j][s] = stream_issue(RL + RG + (j < RS ? j : RS - 1), s);
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) {                                 // the LDS rows, one column step at a time
+            d2 av[RL];
+#pragma unroll
+            for (int i = 0; i < RL; ++i) av[i] = *reinterpret_cast<const d2 *>(lds_A + (size_t)i * pitch + 512 * s + 2 * tid);
+#pragma unroll
+            for (int i = 0; i < RL; ++i) {
+                acc[i] = fma(av[i].x, p[s].x, acc[i]);
+                acc[i] = fma(av[i].y, p[s].y, acc[i]);
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s)                                   // the register rows
+#pragma unroll
+            for (int i = 0; i < RG; ++i) {
+                acc[RL + i] = fma(areg[i][s].x, p[s].x, acc[RL + i]);
+                acc[RL + i] = fma(areg[i][s].y, p[s].y, acc[RL + i]);
+            }
+        if constexpr (RS > 0) {
+#pragma unroll
+            for (int b = 0; b < RS; b += SB) {                        // the streamed rows, SB at a time
+                stream_wait<SB * S>(&sb[0][0]);
+#pragma unroll
+                for (int j = 0; j < SB; ++j)
+                    if (b + j < RS) {
+#pragma unroll
+                        for (int s = 0; s < S; ++s) {
+                            acc[RL + RG + b + j] = fma(sb[j][s].x, p[s].x, acc[RL + RG + b + j]);
+                            acc[RL + RG + b + j] = fma(sb[j][s].y, p[s].y, acc[RL + RG + b + j]);
+                        }
+                    }
+                if (b + SB < RS) {
+#pragma unroll
+                    for (int j = 0; j < SB; ++j)
+#pragma unroll
+                        for (int s = 0; s < S; ++s) sb[j][s] = stream_issue(RL + RG + (b + SB + j < RS ? b + SB + j : RS - 1), s);
+                }
+            }
+        }
+        const int myrow = wave_sum_rows<R>(acc, lane);               // acc[0] = this wave's part of row `myrow`
+        if ((lane & (64 / R - 1)) == 0) red[wave * R + myrow] = acc[0];
+        __syncthreads();
+        if (tid < my_rows && !(k == a.k0 && (int)blockIdx.x == a.mute_wg)) {   // (mute_wg: the test of the bounded waits)
+            const double ap = (red[tid] + red[R + tid]) + (red[2 * R + tid] + red[3 * R + tid]);
+            tagged_put(slot + 2 * (size_t)(row0 + tid), ap, tag);
+        }
+
+        // gather Ap: one watched word first, then the tagged words of all of the thread's columns in one round
+        d2 ap[S];
+        {
+            unsigned need = okmask;
+#pragma unroll
+            for (int s = 0; s < S; ++s) ap[s].x = ap[s].y = 0.0;
+            bool any = need != 0;
+            const long long t0 = wall_clock64();
+            bool expired = false;
+            if (prof) tp[1] = clock64();
+            if (any) {
+                const unsigned long long *watch = slot + 2 * (size_t)(2 * tid);   // column 2 tid: valid whenever `any`
+                for (;;) {
+                    u4 w = tagged_issue(watch);
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(w)::"memory");
+                    ++watch_rounds;
+                    if (w.y == tag && w.w == tag) break;
+                    if (wall_clock64() - t0 > a.timeout_ticks) { expired = true; break; }
+                }
+            }
+            if (prof) tp[2] = clock64();
+            while (any && !expired) {
+                ++gather_rounds;
+                u4 w[2 * S];
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const int c = ((need >> (2 * s)) & 3u) ? 512 * s + 2 * tid : 2 * tid;
+                    w[2 * s] = tagged_issue(slot + 2 * (size_t)c);
+                    w[2 * s + 1] = tagged_issue(slot + 2 * (size_t)c + 2);
+                }
+                tagged_wait<S>(w);
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    if (((need >> (2 * s)) & 1u) && w[2 * s].y == tag && w[2 * s].w == tag) {
+                        ap[s].x = tagged_value(w[2 * s]);
+                        need &= ~(1u << (2 * s));
+                    }
+                    if (((need >> (2 * s + 1)) & 1u) && w[2 * s + 1].y == tag && w[2 * s + 1].w == tag) {
+                        ap[s].y = tagged_value(w[2 * s + 1]);
+                        need &= ~(1u << (2 * s + 1));
+                    }
+                }
+                any = need != 0;
+                if (any && wall_clock64() - t0 > a.timeout_ticks) expired = true;
+            }
+            if (expired) {
+                atomicExch(a.err, 1);
+                *reinterpret_cast<volatile int *>(lds_fail) = 1;
+            }
+        }
+
+        if (prof) tp[3] = clock64();
+        double v = 0.0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) v += p[s].x * ap[s].x + p[s].y * ap[s].y;   // cg.cc:105-106
+        v = wave_sum(v);
+        if (lane == 0) red[4 * R + wave] = v;
+        __syncthreads();
+        if (*reinterpret_cast<volatile int *>(lds_fail)) return;     // uniform: written in front of the barrier
+        const double conj = (red[4 * R] + red[4 * R + 1]) + (red[4 * R + 2] + red[4 * R + 3]);
+        const double alpha = safeguarded_alpha(rsold, conj);         // cg.cc:107
+        if (prof) tp[4] = clock64();
+        double rr = 0.0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            if (s == sx) {                                           // cg.cc:110, the workgroup's own rows
+                xo.x = fma(alpha, p[s].x, xo.x);
+                xo.y = fma(alpha, p[s].y, xo.y);
+            }
+            r[s].x = fma(-alpha, ap[s].x, r[s].x);                   // cg.cc:113
+            r[s].y = fma(-alpha, ap[s].y, r[s].y);
+            rr += r[s].x * r[s].x + r[s].y * r[s].y;                 // cg.cc:116
+        }
+        rr = wave_sum(rr);
+        if (lane == 0) red[4 * R + 4 + wave] = rr;
+        __syncthreads();
+        const double rsnew = (red[4 * R + 4] + red[4 * R + 5]) + (red[4 * R + 6] + red[4 * R + 7]);   // cg.cc:116-117
+        if (prof) {
+            tp[5] = clock64();
+            for (int i = 0; i < 5; ++i) a.prof[i] += tp[i + 1] - tp[i];
+            a.prof[5] += watch_rounds;
+            a.prof[6] += gather_rounds;
+            a.prof[7] += 1;
+        }
+        if (sqrt(rsnew) < a.tol) {                                   // cg.cc:120-121: break before the p update
+            rs_prev = rsnew;
+            stop = 1;
+            break;
+        }
+        const double beta = rsnew / rsold;                           // cg.cc:124
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            p[s].x = fma(beta, p[s].x, r[s].x);                      // cg.cc:127-129
+            p[s].y = fma(beta, p[s].y, r[s].y);
+        }
+        rs_prev = rsold;
+        rsold = rsnew;                                               // cg.cc:132
+    }
+
+    // ---- state back to memory: x by the workgroup that owns the rows, r / p / scalars by workgroup 0
+    if (sx >= 0) {
+        const int c = 512 * sx + 2 * tid;
+        a.x[c] = xo.x;
+        if (c + 1 < row0 + my_rows) a.x[c + 1] = xo.y;
+    }
+    if (blockIdx.x == 0) {
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int c = 512 * s + 2 * tid;
+            if ((okmask >> (2 * s)) & 1u) { a.r[c] = r[s].x; a.p[c] = p[s].x; }
+            if ((okmask >> (2 * s + 1)) & 1u) { a.r[c + 1] = r[s].y; a.p[c + 1] = p[s].y; }
+        }
+        if (tid == 0) {
+            a.sc->rs[k & 1] = rsold;
+            a.sc->rs[(k + 1) & 1] = rs_prev;
+            if (stop) { a.sc->k_final = k; a.sc->done = 1; }
+        }
+    }
+}
+
 // what = 0: launch; 1: prepare (raise the kernel's dynamic-LDS limit, ask the runtime how many workgroups a CU keeps resident)
 template <int R>
 hipError_t with_kernel(const ResidentPlan &pl, const ResidentArgs *a, hipStream_t s, int *per_cu)
@@ -336,8 +659,30 @@ hipError_t with_kernel(const ResidentPlan &pl, const ResidentArgs *a, hipStream_
     return hipErrorInvalidValue;
 }
 
+hipError_t with_hybrid(const ResidentPlan &pl, const ResidentArgs *a, hipStream_t s, int *per_cu)
+{
+    auto go = [&](auto kern) -> hipError_t {
+        if (!a) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               (int)pl.lds_bytes);
+            if (e != hipSuccess) return e;
+            return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kern, kResThreads, pl.lds_bytes);
+        }
+        hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(kResThreads), pl.lds_bytes, s, *a);
+        return hipGetLastError();
+    };
+    switch (pl.S) {
+    case 5: return go(k_cg_hybrid<5>);
+    case 6: return go(k_cg_hybrid<6>);
+    case 7: return go(k_cg_hybrid<7>);
+    case 8: return go(k_cg_hybrid<8>);
+    }
+    return hipErrorInvalidValue;
+}
+
 hipError_t dispatch(const ResidentPlan &pl, const ResidentArgs *a, hipStream_t s, int *per_cu)
 {
+    if (pl.hybrid) return with_hybrid(pl, a, s, per_cu);
     switch (pl.R) {
     case 1: return with_kernel<1>(pl, a, s, per_cu);
     case 2: return with_kernel<2>(pl, a, s, per_cu);
@@ -352,17 +697,31 @@ hipError_t dispatch(const ResidentPlan &pl, const ResidentArgs *a, hipStream_t s
 bool plan_resident(int n, int cus, size_t lds_per_wg, ResidentPlan *out)
 {
     ResidentPlan pl{};
-    if (n < 1 || n > 512 * 4 || cus < 1) return false;
+    if (n < 1 || n > 512 * 8 || cus < 1) return false;
     const int G = cus < 256 ? cus : 256;
+    pl.S = (n + 511) / 512;
+    pl.xslots = 512 * pl.S;
+    if (n > 512 * 4) {
+        // 2048 < n <= 4096: 16 rows per workgroup, RL in LDS + RG in registers + RS streamed per iteration (k_cg_hybrid)
+        pl.hybrid = 1;
+        pl.R = pl.rows_per_wg = kHybR;
+        pl.RL = hyb_rl(pl.S);
+        pl.RG = hyb_rg(pl.S);
+        pl.grid = (n + kHybR - 1) / kHybR;
+        if (pl.grid > G) return false;
+        pl.lds_bytes = ((size_t)pl.RL * pl.S * 512 + 2 * (4 * kHybR + 8) + 8) * sizeof(double);
+        if (pl.lds_bytes > lds_per_wg) return false;
+        *out = pl;
+        return true;
+    }
     pl.R = 1;
     while ((long)pl.R * G < n) pl.R *= 2;
     if (pl.R > 8) return false;
     pl.rows_per_wg = pl.R;
-    pl.S = (n + 511) / 512;
+    pl.RL = pl.R;
     pl.grid = (n + pl.rows_per_wg - 1) / pl.rows_per_wg;
     pl.lds_bytes = ((size_t)pl.rows_per_wg * pl.S * 512 + 2 * (4 * pl.R + 8) + 8) * sizeof(double);
     if (pl.lds_bytes > lds_per_wg) return false;
-    pl.xslots = 512 * pl.S;
     *out = pl;
     return true;
 }

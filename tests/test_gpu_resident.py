@@ -36,7 +36,9 @@ def lap(pkg, n, variant, max_iter=None, tol=None):
     return s
 
 
-SIZES = [3, 7, 64, 255, 256, 257, 511, 512, 513, 1000, 1024, 1025, 1448, 1536, 1537, 2047, 2048]
+SIZES = [3, 7, 64, 255, 256, 257, 511, 512, 513, 1000, 1024, 1025, 1448, 1536, 1537, 2047, 2048,
+         # above 2048: 16 rows per workgroup in LDS + registers + (n > 3072) a rest streamed every iteration
+         2049, 2560, 2561, 2896, 3072, 3073, 3500, 3584, 3585, 4000, 4095, 4096]
 
 
 @pytest.mark.parametrize("n", SIZES)
@@ -48,13 +50,14 @@ def test_fixed_iteration_solve_matches_oracle(gpu_pkg, oracle, n):
         r = s.solve(x)
     xo, ro = oracle.solve_lap2d(n, iters, 0.0, 1)
     assert plan["variant"] == 4 and plan["grid"] <= 256 and plan["R"] * plan["grid"] >= n, plan
+    assert (plan["light"] > 0) == (n > 2048) and (plan["R"] == 16) == (n > 2048), plan
     assert r["iterations"] == ro["iterations"] == iters and not r["converged"]
     assert np.linalg.norm(x - xo) <= 1e-12 * np.linalg.norm(xo)
     assert rel(r["residual_prev"], ro["residual_prev"]) <= 1e-10
     assert rel(r["x_norm"], ro["x_norm"]) <= 1e-12
 
 
-@pytest.mark.parametrize("n", [1, 7, 300, 1000, 1024, 2048])
+@pytest.mark.parametrize("n", [1, 7, 300, 1000, 1024, 2048, 2896, 4096])
 def test_converged_solve(gpu_pkg, oracle, n):
     with lap(gpu_pkg, n, RESIDENT) as s:
         x = np.zeros(n)
@@ -104,8 +107,8 @@ def test_break_semantics_and_resuming(gpu_pkg):
         assert np.array_equal(x, x0)
 
 
-def test_fixed_iterations_in_pieces_are_bit_identical(gpu_pkg):
-    n = 2048
+@pytest.mark.parametrize("n", [2048, 2896, 3584, 4096])
+def test_fixed_iterations_in_pieces_are_bit_identical(gpu_pkg, n):
     runs = []
     for pieces in ([120], [1] * 5 + [115], [60, 60]):
         with lap(gpu_pkg, n, RESIDENT, max_iter=120, tol=0.0) as s:
@@ -131,7 +134,7 @@ def test_max_iter_zero_and_one(gpu_pkg, oracle):
         assert np.linalg.norm(x - xo) <= 1e-13 * max(np.linalg.norm(xo), 1e-300)
 
 
-@pytest.mark.parametrize("n", [777, 1536, 2048])
+@pytest.mark.parametrize("n", [777, 1536, 2048, 2500, 3000, 3600, 4096])
 def test_dense_hash_matrix(gpu_pkg, oracle, n):
     """Every element of the matrix a different number (the generator leaves five non-zeros per row): a lane that read the
     wrong LDS word would show."""
@@ -185,13 +188,13 @@ def test_context_reuse_across_sizes(gpu_pkg):
     """One context, problems of changing size and repeated solves: the exchange buffer is laid out anew (zero-filled) for every
     geometry and the epoch counter only grows, so no solve can read a tagged word of an earlier one."""
     fresh = {}
-    for n in (2048, 1024, 600):
+    for n in (2048, 1024, 600, 3000, 4096):
         with lap(gpu_pkg, n, RESIDENT, 60, 0.0) as s:
             x = np.zeros(n)
             s.solve(x)
             fresh[n] = x
     with gpu_pkg.CGSolver(gemv_variant=RESIDENT) as s:
-        for n in (2048, 1024, 2048, 600, 2048, 1024):
+        for n in (2048, 1024, 4096, 2048, 600, 3000, 2048, 4096, 1024):
             s.generate_lap2d_matrix(n)
             s.set_max_iter(60)
             s.tolerance(0.0)
@@ -208,7 +211,9 @@ def test_selection(gpu_pkg, monkeypatch):
     monkeypatch.delenv("CGX_RESIDENT", raising=False)
     with lap(gpu_pkg, 1024, 0) as s:
         assert s.gemv_plan()["variant"] == 4
-    with lap(gpu_pkg, 2049, 0) as s:
+    with lap(gpu_pkg, 4096, 0) as s:
+        assert s.gemv_plan()["variant"] == 4
+    with lap(gpu_pkg, 4097, 0) as s:
         assert s.gemv_plan()["variant"] == 1
     with lap(gpu_pkg, 1024, 10421) as s:
         assert s.gemv_plan()["variant"] == 1
@@ -221,7 +226,7 @@ def test_selection(gpu_pkg, monkeypatch):
         assert s.gemv_plan()["variant"] == 4
     monkeypatch.delenv("CGX_RESIDENT")
     with pytest.raises(gpu_pkg.CgxError) as e:
-        lap(gpu_pkg, 2049, RESIDENT)
+        lap(gpu_pkg, 4097, RESIDENT)
     assert "does not fit" in str(e.value)
     with gpu_pkg.CGSolver(comm_mode=gpu_pkg.COMM_LOOPBACK, nranks=2, gemv_variant=0) as s:
         s.generate_lap2d_matrix(1024)
@@ -277,10 +282,12 @@ def test_cgsolver_cli_takes_the_resident_path_by_default(gpu_pkg, oracle, tmp_pa
     assert abs(ks["resident"] - ks["launches"]) <= 2
 
 
-def test_epoch_wrap_of_the_tag(gpu_pkg):
+@pytest.mark.parametrize("n", [1448, 3584])
+def test_epoch_wrap_of_the_tag(gpu_pkg, n):
     """The 32-bit tag of the exchange is 1 + epoch mod (2^32 - 1): solves that run across the wrap of the tag, of the epoch's
-    low 32 bits and of twice the period (cgx_probe_resident_test moves the counter there) give the bits of a fresh context."""
-    n, iters = 1448, 80
+    low 32 bits and of twice the period (cgx_probe_resident_test moves the counter there) give the bits of a fresh context.
+    n = 1448: all rows in LDS; n = 3584: LDS + registers + streamed rows."""
+    iters = 80
     with lap(gpu_pkg, n, RESIDENT, iters, 0.0) as s:
         x0 = np.zeros(n)
         r0 = s.solve(x0)
@@ -298,11 +305,11 @@ def test_epoch_wrap_of_the_tag(gpu_pkg):
                 s._resident_test(epoch=start - 1)        # the counter only moves forward
 
 
-def test_a_wait_that_expires_is_reported(gpu_pkg):
+@pytest.mark.parametrize("n", [1024, 4096])
+def test_a_wait_that_expires_is_reported(gpu_pkg, n):
     """Every wait inside the kernel is bounded: a workgroup that never publishes (test hook) makes the waits for it expire after
-    p2p_timeout_ms; the call returns an error instead of hanging, and the context solves again afterwards."""
+    p2p_timeout_ms; the call returns an error instead of hanging, and a new context solves as before."""
     import time
-    n = 1024
     x_good = None
     for mute in (0, 37, 255):
         with gpu_pkg.CGSolver(gemv_variant=RESIDENT, p2p_timeout_ms=200) as s:

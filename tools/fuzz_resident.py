@@ -1,4 +1,4 @@
-"""Randomised parity sweep of the LDS-resident solver (dev tool): random n <= 2048, generated or hash matrix, random b / x0,
+"""Randomised parity sweep of the LDS-resident solver (dev tool): random n <= 4096, generated or hash matrix, random b / x0,
 random number of iterations, the loop cut into random pieces; against the CPU oracle (||dx||/||x||) and, bit for bit,
 against the same solve in one launch.  One context is reused for a run of cases (changing sizes: the exchange buffer is
 laid out anew every time).  python tools/fuzz_resident.py SECONDS [SEED]"""
@@ -14,7 +14,8 @@ s = pkg.CGSolver(gemv_variant=40000)
 while time.time() - t0 < budget:
     if cases % 50 == 49:
         s.close(); s = pkg.CGSolver(gemv_variant=40000)
-    n = int(rng.choice([rng.integers(1, 40), rng.integers(40, 520), rng.integers(500, 1100), rng.integers(1000, 2049), 2048, 1024]))
+    n = int(rng.choice([rng.integers(1, 40), rng.integers(40, 520), rng.integers(500, 1100), rng.integers(1000, 2049), 2048, 1024,
+                        rng.integers(2049, 4097), rng.integers(2049, 4097), 4096, 3072]))
     iters = max(1, min(int(rng.integers(1, 60)), n // 2))
     hashed = n >= 8 and rng.integers(0, 2) == 0
     hseed, hdiag = int(rng.integers(1, 2 ** 62)), 1.03 * 2.0 * (n / 3.0) ** 0.5 + 1.0

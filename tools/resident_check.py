@@ -10,8 +10,8 @@ import __graft_entry__ as g
 pkg = g.load_package()
 from oracle import oracle
 
-sizes = [int(v) for v in os.environ.get("SIZES", "1,2,7,64,300,512,513,1000,1024,1448,2047,2048").split(",")]
-timing = [int(v) for v in os.environ.get("TIMING", "256,512,1024,1448,2048").split(",")]
+sizes = [int(v) for v in os.environ.get("SIZES", "2,7,64,300,512,513,1000,1024,1448,2047,2048,2049,2896,3072,3584,4096").split(",")]
+timing = [int(v) for v in os.environ.get("TIMING", "256,512,1024,1448,2048,2560,2896,3072,3584,4096").split(",")]
 out = []
 for n in sizes:
     for max_iter, tol in ((min(n, 120), 0.0), (None, 1e-10)):
