@@ -90,7 +90,7 @@ def parse_args():
     # argument, not an environment variable: nothing in a user's environment changes what the benchmark does.
     ap.add_argument("--no-reference-sizes", action="store_true",
                     help="skip the extra `reference_sizes` (one GPU, after the measurement: iterations/s at the reference's own "
-                         "small sizes N = 1024 and 2048, LDS-resident kernel beside the per-launch path; ~1 s)")
+                         "sizes N = 1024, 2048 and 4096, the resident persistent kernel beside the per-launch path; ~1 s)")
     ap.add_argument("--test-hang", default="", help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -264,12 +264,12 @@ def cpu_baseline(n, iters):
 
 
 def reference_sizes(pkg, torch):
-    """The reference's own experiment sizes (code/MPI/cg.run:15-44: N = 1024, 2048 ... to convergence or 200 iterations) on this
+    """The reference's own experiment sizes (code/MPI/cg.run:15-44: N = 1024, 2048, 4096 ... to convergence or 200 iterations) on this
     GPU: iterations/s of the loop with the library's default (the LDS-resident persistent kernel) and with
     the per-launch path (K1 + K3 per iteration), tol = 0, 2000 timed iterations after 200, best of 3.  Not the headline metric."""
     import numpy as np
     rows = []
-    for n in (1024, 2048):
+    for n in (1024, 2048, 4096):
         row = {"n": n}
         for name, variant in (("default", 0), ("per_launch", -1)):
             with pkg.CGSolver(gemv_variant=variant) as s:
@@ -288,7 +288,8 @@ def reference_sizes(pkg, torch):
                     best = min(best, (time.perf_counter() - t0) / 2000)
                 s.solve_end()
             row[name] = {"iterations_per_s": 1.0 / best, "us_per_iteration": best * 1e6,
-                         "kernel": "k_cg_resident (one persistent kernel, A in LDS)" if plan["variant"] == 4 else "K1 + K3 per iteration"}
+                         "kernel": ("one persistent kernel, A in LDS" + (" + registers + streamed rest" if plan["light"] else ""))
+                         if plan["variant"] == 4 else "K1 + K3 per iteration"}
         rows.append(row)
     return rows
 

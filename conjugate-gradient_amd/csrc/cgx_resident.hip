@@ -445,6 +445,20 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_hybrid(ResidentArgs a)
     }
     __syncthreads();   // the LDS rows are in place
 
+    // The first batch of streamed rows of an iteration is issued as early as its buffer is free: the rows do not depend on p,
+    // so the loads of iteration k+1 go out right behind the gather of iteration k and are in flight during the two block
+    // reductions, the divisions and the p update.
+    d2 sb[RS > 0 ? SB : 1][S];
+    auto stream_first = [&]() {
+        if constexpr (RS > 0) {
+#pragma unroll
+            for (int j = 0; j < SB; ++j)
+#pragma unroll
+                for (int s = 0; s < S; ++s) sb[j][s] = stream_issue(RL + RG + (j < RS ? j : RS - 1), s);
+        }
+    };
+    stream_first();
+
     int k = a.k0, stop = 0;
     const int k_end = a.k0 + a.iters;
     unsigned long long epoch = a.epoch0;
@@ -462,13 +476,6 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_hybrid(ResidentArgs a)
         double acc[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) acc[i] = 0.0;
-        d2 sb[RS > 0 ? SB : 1][S];
-        if constexpr (RS > 0) {                                       // first batch of streamed rows: in flight during the rest
-#pragma unroll
-            for (int j = 0; j < SB; ++j)
-#pragma unroll
-                for (int s = 0; s < S; ++s) sb[j][s] = stream_issue(RL + RG + (j < RS ? j : RS - 1), s);
-        }
 #pragma unroll
         for (int s = 0; s < S; ++s) {                                 // the LDS rows, one column step at a time
             d2 av[RL];
@@ -567,6 +574,7 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_hybrid(ResidentArgs a)
             }
         }
 
+        stream_first();                                               // for iteration k + 1 (wasted behind the last one)
         if (prof) tp[3] = clock64();
         double v = 0.0;
 #pragma unroll

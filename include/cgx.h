@@ -75,9 +75,10 @@ typedef struct cgx_config {
     int  nranks;              /* number of row blocks (the reference's psize)               */
     unsigned char unique_id[CGX_UNIQUE_ID_BYTES]; /* CGX_COMM_RCCL: from cgx_comm_unique_id */
     int  gemv_variant;        /* 0 = library default: the per-launch path (K1 + K3 per iteration) with the K1 shape chosen from the
-                                 block size -- or, for a dense matrix of n <= 2048 on one GPU (CGX_COMM_SELF), the LDS-resident
+                                 block size -- or, for a dense matrix of n <= 4096 on one GPU (CGX_COMM_SELF), the resident
                                  solver: the whole loop cg.cc:95-137 as ONE persistent kernel, every row group of A held in a
-                                 CU's LDS (csrc/cgx_resident.hip; 3-4 us per iteration instead of 7-12).
+                                 CU's LDS (n <= 2048) or in its LDS and registers with a streamed rest (n <= 4096)
+                                 (csrc/cgx_resident.hip; 3-11 us per iteration instead of 7-26).
                                  40000 = ask for the LDS-resident solver (CGX_ERR_UNSUPPORTED where it cannot be had);
                                  -1 = the per-launch path with its default shape, also where the resident solver would fit
                                  (as does CGX_RESIDENT=0 in the environment); v*10000 + R*100 + U*10 + d = an explicit
@@ -152,8 +153,9 @@ cgx_status  cgx_get_comm_info(cgx_ctx *ctx, int *comm_mode, int *ranks_wired, in
 
 /* The K1 (GEMV, cg.cc:100-102) launch shape the library planned for local shard `local_shard` of the current problem,
  * for the benchmark record (which kernel ran): out = {variant (1 column-split, 2 LDS-staged p tiles, 3 banded, 4 = the loop
- * runs in the LDS-resident persistent kernel), R rows per workgroup (variant 2: per wave), U steps in flight (variant 4:
- * column steps of 512), waves per workgroup, light (1 = the one-round form), split (column pieces per row group, tied to the
+ * runs in the resident persistent kernel), R rows per workgroup (variant 2: per wave), U steps in flight (variant 4:
+ * column steps of 512), waves per workgroup, light (1 = the one-round form; variant 4: rows of a workgroup held in
+ * registers, 0 up to n = 2048), split (column pieces per row group, tied to the
  * XCDs), grid (workgroups of one fused launch; variant 4: of the persistent kernel, all resident at once), ncols (columns
  * swept)}. */
 #define CGX_GEMV_PLAN_INTS 8
@@ -260,7 +262,7 @@ cgx_status  cgx_probe_set_resident_limit(cgx_ctx *ctx, int workgroups);
  * same call between two solves.  A smaller value is refused (flag words only grow). */
 cgx_status  cgx_probe_set_p2p_epoch(cgx_ctx *ctx, int chan, unsigned long long value);
 cgx_status  cgx_probe_get_p2p_epoch(cgx_ctx *ctx, int chan, unsigned long long *value);
-/* TEST ONLY, the LDS-resident solver (gemv_variant 0 / 40000, n <= 2048 on one GPU).  epoch > 0: move the epoch counter of
+/* TEST ONLY, the resident solver (gemv_variant 0 / 40000, n <= 4096 on one GPU).  epoch > 0: move the epoch counter of
  * its tagged-word exchange FORWARD to `epoch` (the next iteration uses epoch + 1), so that tests reach the wrap of the 32-bit
  * tag without 4e9 iterations; a smaller value is refused.  mute_workgroup >= 0: that workgroup of the NEXT launch leaves out the
  * publish of its first iteration, so that every wait for it expires (the bounded-wait path: cgx_solve_steps then returns

@@ -13,7 +13,7 @@ grep speedup $OUT/resident_check.jsonl
 CGX_RESIDENT_PROFILE=1 SIZES=7 TIMING=256,512,1024,1448,2048 timeout -k 10 300 python3 $R/tools/resident_check.py > /dev/null 2> $OUT/phase_profile.err
 grep "resident profile" $OUT/phase_profile.err | awk 'NR%4==0' > $OUT/phase_profile.txt
 cat $OUT/phase_profile.txt
-for N in 1024 1448 2048; do
+for N in 1024 1448 2048 2896 4096; do
   rm -rf /tmp/prof_res_$N
   rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_res_$N -- $R/conjugate-gradient_amd/cgsolver $N /tmp/res_out_$N.txt 2000 > $OUT/cgsolver_n${N}_2000.txt 2>&1
   cp "$(find /tmp/prof_res_$N -name '*kernel_stats.csv' | head -1)" $OUT/cgsolver_n${N}_2000_kernel_stats.csv
