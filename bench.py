@@ -430,7 +430,10 @@ class Bench:
         one rank can never leave the others inside a different torch.distributed call.  Every stage that can block on a
         peer is bounded by --wireup-timeout."""
         pkg, dist, world, rank, n, args = self.pkg, self.dist, self.world, self.rank, self.n, self.args
-        common = dict(nranks=world, rank=rank, device=self.local_rank, gemv_variant=args.variant, lda_pad=args.lda_pad,
+        # the metric and its roofline are defined on the per-launch path (K1 = the dense GEMV kernel): -1 keeps it also for a
+        # --matrix-size of 4096 or less, where the library's default would be the resident persistent kernel (reported
+        # separately as `reference_sizes`)
+        common = dict(nranks=world, rank=rank, device=self.local_rank, gemv_variant=args.variant or -1, lda_pad=args.lda_pad,
                       profile_gemv=self.profile_every, profile_update=bool(self.profile_every) and (world > 1 or args.profile_update))
         box = {"s": None, "uid": None, "handle": None}
         self.state["stage"] = "wire-up of transport " + transport
