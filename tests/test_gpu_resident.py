@@ -387,3 +387,61 @@ def test_two_processes_and_two_threads_at_once(gpu_pkg):
         t.join()
     assert not errors, errors
     assert np.array_equal(results[0], results[1])
+
+
+@pytest.mark.parametrize("n", [1024, 3584])
+def test_error_paths_of_a_resident_solve(gpu_pkg, n):
+    """Every HIP call of setting a problem and of a whole solve through the resident kernel is made to fail in turn
+    (cgx_probe_set_fault_after): the call reports an error, the device's free memory is back where it was, and the same
+    context then solves to the same bits."""
+    import torch
+
+    def free_mb():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0] / 2**20
+
+    def problem(s):
+        s.generate_lap2d_matrix(n)
+        s.set_max_iter(60)
+        s.tolerance(0.0)
+        s.init_source_term(1.0 / n)
+
+    with gpu_pkg.CGSolver(gemv_variant=RESIDENT) as s:
+        problem(s)
+        assert s.gemv_plan()["variant"] == 4
+        x_good = np.zeros(n)
+        s.solve(x_good)
+        base, failures = free_mb(), 0
+        for k in range(200):
+            s._set_fault_after(k)
+            try:
+                x = np.zeros(n)
+                s.solve(x)
+                s._set_fault_after(-1)
+                break                                        # k is past the last HIP call of a solve
+            except gpu_pkg.CgxError as e:
+                assert e.status in (3, 5), e
+                failures += 1
+            s._set_fault_after(-1)
+            assert abs(free_mb() - base) < 2, k
+        assert failures >= 10 and np.array_equal(x, x_good)
+        x = np.zeros(n)
+        s.solve(x)
+        assert np.array_equal(x, x_good)
+    # the same over the calls that set the problem (a new geometry every time: n - 16, then n again)
+    with gpu_pkg.CGSolver(gemv_variant=RESIDENT) as s:
+        failures = 0
+        for k in range(200):
+            s.generate_lap2d_matrix(n - 16)
+            s._set_fault_after(k)
+            try:
+                problem(s)
+                s._set_fault_after(-1)
+                break
+            except gpu_pkg.CgxError:
+                failures += 1
+            s._set_fault_after(-1)
+        assert failures >= 5
+        x = np.zeros(n)
+        s.solve(x)
+        assert np.array_equal(x, x_good)
