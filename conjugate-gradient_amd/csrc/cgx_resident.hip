@@ -379,8 +379,9 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_hybrid(ResidentArgs a)
 
     // The streamed rows are loaded with ONE 32-bit byte offset per column step (shared by all rows) on a workgroup-uniform row
     // base in SGPRs: left to the compiler, the RS x S 64-bit addresses are hoisted out of the iteration loop and held in
-    // VGPRs (seen as 900 bytes of scratch per lane).  A column step that reaches behind the pitch reads the row's last pair of
-    // pad columns instead -- zero in the block by construction, and multiplied by p = 0 there.
+    // VGPRs (seen as 900 bytes of scratch per lane).  A column step that reaches behind the pitch reads the last pair of
+    // columns inside the pitch instead: with the default pitch those are pad columns (zero by construction); with lda_pad = 0
+    // they may be real entries -- either way the product is with p = 0 (the thread's own column is >= n), i.e. exactly 0.
     unsigned soff[S];
 #pragma unroll
     for (int s = 0; s < S; ++s) {

@@ -445,3 +445,23 @@ def test_error_paths_of_a_resident_solve(gpu_pkg, n):
         x = np.zeros(n)
         s.solve(x)
         assert np.array_equal(x, x_good)
+
+
+@pytest.mark.parametrize("n,lda_pad", [(2896, 0), (2896, 2), (3584, 0), (4096, 0), (1448, 0), (3000, 6)])
+def test_other_row_pitches(gpu_pkg, oracle, n, lda_pad):
+    """cgx_config.lda_pad = 0: the pitch is roundup(n, 16) with no pad columns behind it, so a column step of the streamed /
+    register / LDS rows that reaches behind the pitch lands on real entries of a dense matrix: they must not count."""
+    seed, it = 99 + n, 20
+    diag = 1.03 * 2.0 * (n / 3.0) ** 0.5
+    with gpu_pkg.CGSolver(gemv_variant=RESIDENT, lda_pad=lda_pad) as s:
+        s.generate_lap2d_matrix(n)
+        s.probe_fill_matrix_hash(seed, symmetric=True, diag=diag)
+        s.set_max_iter(it)
+        s.tolerance(0.0)
+        s.init_source_term(1.0 / n)
+        x = np.zeros(n)
+        r = s.solve(x)
+    xo, ro = oracle.solve(oracle.hash_rows(n, 0, n, seed, True, diag), oracle.init_source_term(n), max_iter=it, tol=0.0)
+    assert r["iterations"] == ro["iterations"] == it
+    assert np.linalg.norm(x - xo) <= 1e-12 * np.linalg.norm(xo)
+    assert rel(r["residual_prev"], ro["residual_prev"]) <= 1e-10
