@@ -23,9 +23,9 @@
 // Measured on one MI355X (tools/resident_check.py, profiles/r04_resident/): 3.0-3.5 us per iteration for n <= 1448, 4.0 us at
 // n = 2048, against 7-12 us of the per-launch path.  Where the time goes (CGX_RESIDENT_PROFILE=1, workgroup 0): ~1.0-1.5 us
 // until the watched word of another workgroup has arrived (store -> memory -> load, plus the skew between workgroups),
-// 0.3-1.0 us for the gather round (at n = 2048 every workgroup reads 32 KB = 8 MB per iteration over the fabric: XCD L2s are
-// not coherent with each other, so a word written on another XCD can only come from memory), 0.3-0.6 us for the LDS GEMV and
-// its row sums, 0.7 us for the two block reductions and the scalar divisions.
+// 0.3-1.0 us for the gather round (at n = 2048 every workgroup asks for 32 KB of tagged words; by FETCH_SIZE about one copy
+// per XCD and iteration leaves the L2s, so the round is bound by the L2s' request rate, profiles/r04_resident/pmc/),
+// 0.3-0.6 us for the LDS GEMV and its row sums, 0.7 us for the two block reductions and the scalar divisions.
 //
 // Two parities of the exchange buffer suffice: a workgroup publishes epoch e+2 only after it has read every workgroup's e+1,
 // which those publish only after they have read all of e.  Every wait is bounded by the wall clock (cgx_config.p2p_timeout_ms,

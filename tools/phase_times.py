@@ -2,7 +2,7 @@ import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 pkg = g.load_package()
-for n in (2048, 4096, 8192, 32768):
+for n in [int(v) for v in os.environ.get("SIZES", "1024,2048,4096,8192,32768").split(",")]:
     with pkg.CGSolver() as s:
         s.generate_lap2d_matrix(n); s.init_source_term(1.0 / n); s.set_max_iter(300); s.tolerance(0.0)
         for rep in range(3):
