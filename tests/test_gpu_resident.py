@@ -465,3 +465,36 @@ def test_other_row_pitches(gpu_pkg, oracle, n, lda_pad):
     assert r["iterations"] == ro["iterations"] == it
     assert np.linalg.norm(x - xo) <= 1e-12 * np.linalg.norm(xo)
     assert rel(r["residual_prev"], ro["residual_prev"]) <= 1e-10
+
+
+def test_matrix_market_input(gpu_pkg, oracle, tmp_path):
+    """MatrixCOO::read + Matrix::read (matrix_coo.cc:7-60, matrix.cc:6-22) into a problem the resident kernel takes: a
+    symmetric coordinate file of n = 300 and a general one of n = 2500, against the oracle's reader + solve."""
+    rng = np.random.default_rng(8)
+    for n, sym in ((300, True), (2500, False)):
+        path = tmp_path / ("m%d.mtx" % n)
+        entries = []
+        for i in range(n):
+            entries.append((i, i, 4.0 + rng.random()))
+            for j in (i - 1, i - 17):
+                if j >= 0:
+                    v = -rng.random()
+                    entries.append((i, j, v))
+                    if not sym:
+                        entries.append((j, i, v))
+        with open(path, "w") as f:
+            f.write("%%%%MatrixMarket matrix coordinate real %s\n%d %d %d\n" % ("symmetric" if sym else "general", n, n, len(entries)))
+            for i, j, v in entries:
+                f.write("%d %d %.17g\n" % (i + 1, j + 1, v))
+        A = oracle.read_mtx_dense(str(path))[0]
+        b = oracle.init_source_term(n)
+        with gpu_pkg.CGSolver(gemv_variant=RESIDENT) as s:
+            s.read_matrix(str(path))
+            assert s.gemv_plan()["variant"] == 4
+            s.set_max_iter(30)
+            s.tolerance(0.0)
+            s.init_source_term(1.0 / n)
+            x = np.zeros(n)
+            r = s.solve(x)
+        xo, ro = oracle.solve(A, b, None, 30, 0.0, 1)
+        assert np.linalg.norm(x - xo) <= 1e-12 * np.linalg.norm(xo) and rel(r["residual_prev"], ro["residual_prev"]) <= 1e-10
