@@ -91,6 +91,15 @@ __device__ __forceinline__ void stream_wait(d2 *v)
     for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i])::"memory");
 }
 
+// Where the tagged double of column c sits in a parity of the exchange buffer: inside each block of 128 columns the even ones
+// first, then the odd ones.  A thread owns the column pair (c, c + 1) (its LDS reads are 16-byte pairs of adjacent columns), so
+// with this layout the 64 lanes of a wave fetch their even columns with ONE fully coalesced 1-KiB load and their odd columns
+// with another, instead of two loads that each touch half of 16 lines.
+__device__ __forceinline__ int xpos(int c)
+{
+    return (c & ~127) | ((c & 1) << 6) | ((c & 127) >> 1);
+}
+
 __device__ __forceinline__ double tagged_value(const u4 &w)
 {
     return __longlong_as_double((long long)((unsigned long long)w.x | ((unsigned long long)w.z << 32)));
@@ -205,7 +214,7 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
         __syncthreads();
         if (tid < my_rows && !(k == a.k0 && (int)blockIdx.x == a.mute_wg)) {   // (mute_wg: the test of the bounded waits)
             const double ap = (red[tid] + red[R + tid]) + (red[2 * R + tid] + red[3 * R + tid]);
-            tagged_put(slot + 2 * (size_t)(row0 + tid), ap, tag);
+            tagged_put(slot + 2 * (size_t)xpos(row0 + tid), ap, tag);
         }
 
         // gather Ap: every thread polls the tagged words of its own columns.  First ONE of them (16 bytes per thread and
@@ -226,7 +235,7 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
             bool expired = false;
             if (prof) tp[1] = clock64();
             if (any) {
-                const unsigned long long *watch = slot + 2 * (size_t)(2 * tid);   // column 2 tid: valid whenever `any`
+                const unsigned long long *watch = slot + 2 * (size_t)xpos(2 * tid);   // column 2 tid: valid whenever `any`
                 for (;;) {
                     u4 w = tagged_issue(watch);
                     asm volatile("s_waitcnt vmcnt(0)" : "+v"(w)::"memory");
@@ -243,8 +252,8 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
                 for (int s = 0; s < S; ++s) {
                     // a column that is not needed (any more) re-reads a word of this thread's first pair: a mapped address
                     const int c = (need0[s] || need1[s]) ? 512 * s + 2 * tid : 2 * tid;
-                    w[2 * s] = tagged_issue(slot + 2 * (size_t)c);
-                    w[2 * s + 1] = tagged_issue(slot + 2 * (size_t)c + 2);
+                    w[2 * s] = tagged_issue(slot + 2 * (size_t)xpos(c));
+                    w[2 * s + 1] = tagged_issue(slot + 2 * (size_t)xpos(c + 1));
                 }
                 tagged_wait<S>(w);
                 any = false;
@@ -521,7 +530,7 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_hybrid(ResidentArgs a)
         __syncthreads();
         if (tid < my_rows && !(k == a.k0 && (int)blockIdx.x == a.mute_wg)) {   // (mute_wg: the test of the bounded waits)
             const double ap = (red[tid] + red[R + tid]) + (red[2 * R + tid] + red[3 * R + tid]);
-            tagged_put(slot + 2 * (size_t)(row0 + tid), ap, tag);
+            tagged_put(slot + 2 * (size_t)xpos(row0 + tid), ap, tag);
         }
 
         // gather Ap: one watched word first, then the tagged words of all of the thread's columns in one round
@@ -535,7 +544,7 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_hybrid(ResidentArgs a)
             bool expired = false;
             if (prof) tp[1] = clock64();
             if (any) {
-                const unsigned long long *watch = slot + 2 * (size_t)(2 * tid);   // column 2 tid: valid whenever `any`
+                const unsigned long long *watch = slot + 2 * (size_t)xpos(2 * tid);   // column 2 tid: valid whenever `any`
                 for (;;) {
                     u4 w = tagged_issue(watch);
                     asm volatile("s_waitcnt vmcnt(0)" : "+v"(w)::"memory");
@@ -551,8 +560,8 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_hybrid(ResidentArgs a)
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
                     const int c = ((need >> (2 * s)) & 3u) ? 512 * s + 2 * tid : 2 * tid;
-                    w[2 * s] = tagged_issue(slot + 2 * (size_t)c);
-                    w[2 * s + 1] = tagged_issue(slot + 2 * (size_t)c + 2);
+                    w[2 * s] = tagged_issue(slot + 2 * (size_t)xpos(c));
+                    w[2 * s + 1] = tagged_issue(slot + 2 * (size_t)xpos(c + 1));
                 }
                 tagged_wait<S>(w);
 #pragma unroll
