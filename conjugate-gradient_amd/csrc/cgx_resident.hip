@@ -486,15 +486,27 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_hybrid(ResidentArgs a)
         double acc[R];
 #pragma unroll
         for (int i = 0; i < R; ++i) acc[i] = 0.0;
+        // the LDS rows, one column step at a time: the RL reads of a step are issued together, and the reads of the next step go
+        // out before the FMAs of this one (sched_barrier: left to itself the compiler reuses one destination register quad and
+        // the loop becomes read / wait / fma triples -- 35 exposed LDS latencies at S = 5, seen in the ISA and in the profile)
+        {
+            d2 av[2][RL];
 #pragma unroll
-        for (int s = 0; s < S; ++s) {                                 // the LDS rows, one column step at a time
-            d2 av[RL];
+            for (int i = 0; i < RL; ++i) av[0][i] = *reinterpret_cast<const d2 *>(lds_A + (size_t)i * pitch + 2 * tid);
 #pragma unroll
-            for (int i = 0; i < RL; ++i) av[i] = *reinterpret_cast<const d2 *>(lds_A + (size_t)i * pitch + 512 * s + 2 * tid);
+            for (int s = 0; s < S; ++s) {
+                if (s + 1 < S) {
 #pragma unroll
-            for (int i = 0; i < RL; ++i) {
-                acc[i] = fma(av[i].x, p[s].x, acc[i]);
-                acc[i] = fma(av[i].y, p[s].y, acc[i]);
+                    for (int i = 0; i < RL; ++i)
+                        av[(s + 1) & 1][i] = *reinterpret_cast<const d2 *>(lds_A + (size_t)i * pitch + 512 * (s + 1) + 2 * tid);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < RL; ++i) {
+                    acc[i] = fma(av[s & 1][i].x, p[s].x, acc[i]);
+                    acc[i] = fma(av[s & 1][i].y, p[s].y, acc[i]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
 #pragma unroll
