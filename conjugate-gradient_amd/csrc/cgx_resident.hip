@@ -347,14 +347,14 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
 // places: RL rows in LDS (as above), RG rows in REGISTERS (thread t holds its own 2 S columns of each: 4 S VGPRs per row, loaded
 // once per launch), and the remaining RS rows streamed from memory every iteration (non-temporal 16-byte loads, two rows per
 // batch, the first batch in flight while the LDS and register rows are multiplied).  S = 5: 7 + 9 + 0 (all resident, n <= 2560);
-// S = 6: 6 + 10 + 0 (all resident, n <= 3072); S = 7: 5 + 6 + 5; S = 8: 4 + 6 + 6 (n = 4096: 48 of 128 MiB re-read per iteration).
+// S = 6: 6 + 10 + 0 (all resident, n <= 3072); S = 7: 5 + 9 + 2; S = 8: 4 + 8 + 4 (n = 4096: 32 of 128 MiB re-read per iteration).
 // x is not replicated here: a workgroup keeps x for its own 16 rows only (nobody else needs it), r and p stay replicated.
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int kHybR = 16;
 constexpr int hyb_rl(int S) { return (150 * 1024) / (S * 512 * 8) < kHybR ? (150 * 1024) / (S * 512 * 8) : kHybR; }
 // rows in registers: what the 512 registers of a thread hold beside r, p, the row sums, a batch of streamed rows and the
-// gather's words without a byte of scratch (hipcc 7.2: 364 / 451 / 481 / 501 registers at S = 5 / 6 / 7 / 8)
-constexpr int hyb_rg(int S) { return S == 5 ? 9 : S == 6 ? 10 : 6; }
+// gather's words without a byte of scratch (hipcc 7.2: 364 / 446 / 487 / 511 registers at S = 5 / 6 / 7 / 8)
+constexpr int hyb_rg(int S) { return S == 5 ? 9 : S == 6 ? 10 : S == 7 ? 9 : 8; }
 #define HYB_SB 2
 
 template <int S>
