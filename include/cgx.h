@@ -78,7 +78,7 @@ typedef struct cgx_config {
                                  block size -- or, for a dense matrix of n <= 4096 on one GPU (CGX_COMM_SELF), the resident
                                  solver: the whole loop cg.cc:95-137 as ONE persistent kernel, every row group of A held in a
                                  CU's LDS (n <= 2048) or in its LDS and registers with a streamed rest (n <= 4096)
-                                 (csrc/cgx_resident.hip; 3-11 us per iteration instead of 7-26).
+                                 (csrc/cgx_resident.hip; 3-9 us per iteration instead of 7-26).
                                  40000 = ask for the LDS-resident solver (CGX_ERR_UNSUPPORTED where it cannot be had);
                                  -1 = the per-launch path with its default shape, also where the resident solver would fit
                                  (as does CGX_RESIDENT=0 in the environment); v*10000 + R*100 + U*10 + d = an explicit
