@@ -254,7 +254,7 @@ struct ResidentPlan {
     int grid;          // workgroups = ceil(n / R) <= CUs
     int xslots;        // tagged doubles per parity of the exchange buffer (512 * S)
     size_t lds_bytes;  // dynamic LDS of one workgroup
-    int hybrid;        // 1 = 2048 < n <= 4096 (k_cg_hybrid): R = 16 rows per workgroup, of which RL in LDS, RG in registers and
+    int hybrid;        // 1 = 2048 < n <= 4096: R = 16 rows per workgroup, of which RL in LDS, RG in registers and
     int RL, RG;        //     R - RL - RG streamed from memory every iteration; 0: all R rows in LDS (RL = R, RG = 0)
 };
 struct ResidentArgs {

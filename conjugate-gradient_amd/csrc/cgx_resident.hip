@@ -1,31 +1,34 @@
-// cgx_resident.hip -- the whole CG loop of code/MPI/cg.cc:95-137 as ONE persistent kernel for matrices that fit the chip's LDS.
+// cgx_resident.hip -- the whole CG loop of code/MPI/cg.cc:95-137 as ONE persistent kernel for matrices that fit on the chip.
 //
 // The reference's own experiment sizes start at N = 1024, 1448, 2048 (code/MPI/cg.run:15-44, results/strong_scaling.txt,
 // results/weak_scaling.txt).  There the per-launch path (K1 + K3 per iteration) is bound by two kernel boundaries and two
 // launch ramps per iteration (8-12 us), not by memory.  An MI355X has 256 CUs x 160 KB of LDS = 40 MB: an n x n fp64 matrix
-// with n <= 2048 (32 MB) fits, one row group per CU, and never has to be read again after the first iteration.
+// with n <= 2048 (32 MB) fits, one row group per CU, and never has to be read again after the first iteration; up to n = 4096
+// (128 MiB) the CUs' 512 KB register files hold most of the rest.
 //
 //   grid  = G workgroups of 256 threads, G = ceil(n / R) <= 256, ALL resident (one per CU: the LDS footprint allows no second);
-//   LDS   = the workgroup's R rows of A (R = the power of two with R x 256 >= n: 4 at n = 1024, 8 at 1448 and 2048),
-//           row-major at a pitch of S x 512 doubles, columns >= n zero;
-//   state = x, r, p REPLICATED in every workgroup, held in registers: thread t owns the column pairs {512 s + 2 t, + 1},
-//           s < S -- the same columns whose A entries it reads from LDS, so the GEMV needs no vector traffic at all;
+//   A     = the workgroup's R rows (n <= 2048: R = the power of two with R x 256 >= n, 4 at n = 1024, 8 at 1448 and 2048, all of
+//           them in LDS, row-major at a pitch of S x 512 doubles; 2048 < n <= 4096: R = 16, of which RL in LDS, RG in registers
+//           and the remaining RS streamed from memory every iteration -- the table in front of the kernel);
+//   state = r, p REPLICATED in every workgroup, held in registers: thread t owns the column pairs {512 s + 2 t, + 1}, s < S --
+//           the same columns whose A entries it reads from LDS / holds in registers / streams, so the GEMV needs no vector
+//           traffic at all; x only for the workgroup's own rows (nobody else needs it);
 //   one iteration (cg.cc:96-137) =
-//     Ap_sub = A_sub p            R x S ds_read_b128 + 2 R S fma per thread, row sums by DPP + one LDS combine   cg.cc:100-102
-//     publish Ap_sub              <= 8 doubles per workgroup as tagged words ({32 bits of the value | 32-bit tag of the epoch}
+//     Ap_sub = A_sub p            2 R S fma per thread, row sums by DPP + one LDS combine                         cg.cc:100-102
+//     publish Ap_sub              <= 16 doubles per workgroup as tagged words ({32 bits of the value | 32-bit tag of the epoch}
 //                                 twice, cgx_device.h), ONE 16-byte agent-scope write-through store per double
 //     gather Ap                   every thread polls the tagged words of its own 2 S columns (sc1 loads): every word
 //                                 validates itself, so there is no flag, no fence and no grid barrier
 //     p.Ap, alpha                 every workgroup over the whole vectors, same order: bit-identical everywhere    cg.cc:105-107
-//     x += alpha p, r -= alpha Ap, r.r, break test, beta, p = r + beta p                                          cg.cc:110-132
+//     x += alpha p (own rows), r -= alpha Ap, r.r, break test, beta, p = r + beta p                               cg.cc:110-132
 //   so what travels is Ap -- exactly the design of the multi-GPU exchange (cgx_kernels.hip), with CUs in place of GPUs.
 //
-// Measured on one MI355X (tools/resident_check.py, profiles/r04_resident/): 3.0-3.5 us per iteration for n <= 1448, 4.0 us at
-// n = 2048, against 7-12 us of the per-launch path.  Where the time goes (CGX_RESIDENT_PROFILE=1, workgroup 0): ~1.0-1.5 us
+// Measured on one MI355X (tools/resident_check.py, profiles/r04_resident/): 3.3-4.1 us per iteration for n <= 2048, 4.5-8.7 us
+// up to n = 4096, against 7-26 us of the per-launch path.  Where the time goes (CGX_RESIDENT_PROFILE=1, workgroup 0): ~1.0-1.5 us
 // until the watched word of another workgroup has arrived (store -> memory -> load, plus the skew between workgroups),
-// 0.3-1.0 us for the gather round (at n = 2048 every workgroup asks for 32 KB of tagged words; by FETCH_SIZE about one copy
-// per XCD and iteration leaves the L2s, so the round is bound by the L2s' request rate, profiles/r04_resident/pmc/),
-// 0.3-0.6 us for the LDS GEMV and its row sums, 0.7 us for the two block reductions and the scalar divisions.
+// 0.3-1.7 us for the gather round (at n = 2048 every workgroup asks for 32 KB of tagged words; by FETCH_SIZE about one copy
+// per XCD and iteration leaves the L2s, profiles/r04_resident/pmc/), 0.4-3.6 us for the GEMV and its row sums (the top end:
+// n = 4096 with 32 MiB streamed), 0.7-1.9 us for the two block reductions and the scalar divisions.
 //
 // Two parities of the exchange buffer suffice: a workgroup publishes epoch e+2 only after it has read every workgroup's e+1,
 // which those publish only after they have read all of e.  Every wait is bounded by the wall clock (cgx_config.p2p_timeout_ms,
@@ -105,250 +108,14 @@ __device__ __forceinline__ double tagged_value(const u4 &w)
     return __longlong_as_double((long long)((unsigned long long)w.x | ((unsigned long long)w.z << 32)));
 }
 
-// R = rows per workgroup, a power of two (the row sums are reduced together, wave_sum_rows); the last workgroup may own fewer
-// (the rest of its LDS rows are zero).  S = column steps of 512.
-template <int R, int S>
-__global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
-{
-    extern __shared__ double lds_all[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = a.n;
-    constexpr int Rr = R;
-    const int pitch = S * 512;
-    double *lds_A = lds_all;                      // Rr x pitch
-    constexpr int kScratch = 4 * R + 8;
-    double *lds_red = lds_all + (size_t)Rr * pitch;   // two sets of per-iteration scratch (see the loop)
-    double *lds_sum = lds_red + 2 * kScratch;         // 4 doubles for block_sum (set-up only)
-    double *lds_fail = lds_sum + 4;                   // one word: a wait of this workgroup expired
-    const int row0 = blockIdx.x * Rr;
-    const int my_rows = min(Rr, n - row0);        // >= 1 by construction of the grid
-
-    if (tid == 0) *reinterpret_cast<volatile int *>(lds_fail) = 0;
-    if (__syncthreads_or(__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return;
-
-    // ---- A_sub -> LDS, once per launch (16-B pieces; the block's pad columns up to lda are zero already, beyond that: zero here)
-    for (int r = 0; r < Rr; ++r) {
-        const bool real = r < my_rows;
-        const double *src = a.A + (size_t)(row0 + (real ? r : 0)) * a.lda;
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const int c = 512 * s + 2 * tid;
-            d2 v = {0.0, 0.0};
-            if (real && c < a.lda) v = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(src + c));
-            if (c >= n) v.x = 0.0;
-            if (c + 1 >= n) v.y = 0.0;
-            *reinterpret_cast<d2 *>(lds_A + (size_t)r * pitch + c) = v;
-        }
-    }
-
-    // ---- state: x, r, p for this thread's columns
-    d2 x[S], r[S], p[S];
-    bool ok0[S], ok1[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) {
-        const int c = 512 * s + 2 * tid;
-        ok0[s] = c < n;
-        ok1[s] = c + 1 < n;
-        x[s].x = ok0[s] ? a.x[c] : 0.0;
-        x[s].y = ok1[s] ? a.x[c + 1] : 0.0;
-        r[s].x = ok0[s] ? a.r[c] : 0.0;
-        r[s].y = ok1[s] ? a.r[c + 1] : 0.0;
-        if (a.k0 > 0) {
-            p[s].x = ok0[s] ? a.p[c] : 0.0;
-            p[s].y = ok1[s] ? a.p[c + 1] : 0.0;
-        } else {
-            p[s] = r[s];                                              // p = r, cg.cc:85
-        }
-    }
-    double rsold, rs_prev;
-    if (a.k0 > 0) {
-        rsold = a.sc->rs[a.k0 & 1];
-        rs_prev = a.sc->rs[(a.k0 + 1) & 1];
-    } else {
-        double v = 0.0;
-#pragma unroll
-        for (int s = 0; s < S; ++s) v += r[s].x * p[s].x + r[s].y * p[s].y;   // rsold = r.p, cg.cc:91-92
-        rsold = block_sum<4>(v, lds_sum);
-        rs_prev = rsold;
-    }
-    __syncthreads();   // A_sub is in LDS
-
-    int k = a.k0, stop = 0;
-    const int k_end = a.k0 + a.iters;
-    unsigned long long epoch = a.epoch0;
-    for (; k < k_end; ++k) {
-        ++epoch;
-        const unsigned tag = p2p_tag(epoch);
-        unsigned long long *slot = a.xbuf + (size_t)(epoch & 1) * (2 * a.xslots);
-        // LDS scratch of this iteration: two sets, used alternately, so that a reduction needs ONE barrier (the values of
-        // iteration k are read before the barrier of iteration k+1 that precedes the next write to the same set)
-        double *red = lds_red + (k & 1) * kScratch;     // [4 waves][R] row sums | [4] p.Ap | [4] r.r
-        const bool prof = a.prof != nullptr && blockIdx.x == 0 && tid == 0;
-        long long tp[6] = {0, 0, 0, 0, 0, 0};
-        int watch_rounds = 0, gather_rounds = 0;
-        if (prof) tp[0] = clock64();
-
-        // Ap_sub = A_sub p (cblas_dgemv, cg.cc:100-102): the thread's columns of every row, ascending
-        // all R x S LDS reads are issued before the first fma (sched_barrier: left to itself the compiler reuses one
-        // destination register quad and the loop becomes read / wait / fma pairs, seen in the ISA)
-        d2 av[S][R];
-#pragma unroll
-        for (int s = 0; s < S; ++s)
-#pragma unroll
-            for (int i = 0; i < R; ++i)
-                av[s][i] = *reinterpret_cast<const d2 *>(lds_A + (size_t)i * pitch + 512 * s + 2 * tid);
-        __builtin_amdgcn_sched_barrier(0);
-        double acc[R];
-#pragma unroll
-        for (int i = 0; i < R; ++i) acc[i] = 0.0;
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-#pragma unroll
-            for (int i = 0; i < R; ++i) {
-                acc[i] = fma(av[s][i].x, p[s].x, acc[i]);
-                acc[i] = fma(av[s][i].y, p[s].y, acc[i]);
-            }
-        }
-        const int myrow = wave_sum_rows<R>(acc, lane);               // acc[0] = this wave's part of row `myrow`
-        if ((lane & (64 / R - 1)) == 0) red[wave * R + myrow] = acc[0];
-        __syncthreads();
-        if (tid < my_rows && !(k == a.k0 && (int)blockIdx.x == a.mute_wg)) {   // (mute_wg: the test of the bounded waits)
-            const double ap = (red[tid] + red[R + tid]) + (red[2 * R + tid] + red[3 * R + tid]);
-            tagged_put(slot + 2 * (size_t)xpos(row0 + tid), ap, tag);
-        }
-
-        // gather Ap: every thread polls the tagged words of its own columns.  First ONE of them (16 bytes per thread and
-        // round: the words of a round that comes too early are thrown away, and a full round is 32 bytes x n per workgroup
-        // through the fabric), then all of them, every load of a round in flight together.
-        d2 ap[S];
-        {
-            bool need0[S], need1[S];
-            bool any = false;
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                need0[s] = ok0[s];
-                need1[s] = ok1[s];
-                ap[s].x = ap[s].y = 0.0;
-                any = any || need0[s];
-            }
-            const long long t0 = wall_clock64();
-            bool expired = false;
-            if (prof) tp[1] = clock64();
-            if (any) {
-                const unsigned long long *watch = slot + 2 * (size_t)xpos(2 * tid);   // column 2 tid: valid whenever `any`
-                for (;;) {
-                    u4 w = tagged_issue(watch);
-                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(w)::"memory");
-                    ++watch_rounds;
-                    if (w.y == tag && w.w == tag) break;
-                    if (wall_clock64() - t0 > a.timeout_ticks) { expired = true; break; }
-                }
-            }
-            if (prof) tp[2] = clock64();
-            while (any && !expired) {
-                ++gather_rounds;
-                u4 w[2 * S];
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    // a column that is not needed (any more) re-reads a word of this thread's first pair: a mapped address
-                    const int c = (need0[s] || need1[s]) ? 512 * s + 2 * tid : 2 * tid;
-                    w[2 * s] = tagged_issue(slot + 2 * (size_t)xpos(c));
-                    w[2 * s + 1] = tagged_issue(slot + 2 * (size_t)xpos(c + 1));
-                }
-                tagged_wait<S>(w);
-                any = false;
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    if (need0[s] && w[2 * s].y == tag && w[2 * s].w == tag) {
-                        ap[s].x = tagged_value(w[2 * s]);
-                        need0[s] = false;
-                    }
-                    if (need1[s] && w[2 * s + 1].y == tag && w[2 * s + 1].w == tag) {
-                        ap[s].y = tagged_value(w[2 * s + 1]);
-                        need1[s] = false;
-                    }
-                    any = any || need0[s] || need1[s];
-                }
-                if (any && wall_clock64() - t0 > a.timeout_ticks) expired = true;
-            }
-            if (expired) {                                           // bounded: give up, tell the host and the workgroup
-                atomicExch(a.err, 1);
-                *reinterpret_cast<volatile int *>(lds_fail) = 1;
-            }
-        }
-
-        if (prof) tp[3] = clock64();
-        // p.Ap over all n rows (cblas_ddot + MPI_Allreduce, cg.cc:105-106), alpha (cg.cc:107)
-        double v = 0.0;
-#pragma unroll
-        for (int s = 0; s < S; ++s) v += p[s].x * ap[s].x + p[s].y * ap[s].y;
-        v = wave_sum(v);
-        if (lane == 0) red[4 * R + wave] = v;
-        __syncthreads();
-        if (*reinterpret_cast<volatile int *>(lds_fail)) return;     // uniform: written in front of the barrier
-        const double conj = (red[4 * R] + red[4 * R + 1]) + (red[4 * R + 2] + red[4 * R + 3]);
-        const double alpha = safeguarded_alpha(rsold, conj);
-        if (prof) tp[4] = clock64();
-        double rr = 0.0;
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            x[s].x = fma(alpha, p[s].x, x[s].x);                     // cg.cc:110
-            x[s].y = fma(alpha, p[s].y, x[s].y);
-            r[s].x = fma(-alpha, ap[s].x, r[s].x);                   // cg.cc:113
-            r[s].y = fma(-alpha, ap[s].y, r[s].y);
-            rr += r[s].x * r[s].x + r[s].y * r[s].y;                 // cg.cc:116
-        }
-        rr = wave_sum(rr);
-        if (lane == 0) red[4 * R + 4 + wave] = rr;
-        __syncthreads();
-        const double rsnew = (red[4 * R + 4] + red[4 * R + 5]) + (red[4 * R + 6] + red[4 * R + 7]);   // cg.cc:116-117
-        if (prof) {
-            tp[5] = clock64();
-            for (int i = 0; i < 5; ++i) a.prof[i] += tp[i + 1] - tp[i];
-            a.prof[5] += watch_rounds;
-            a.prof[6] += gather_rounds;
-            a.prof[7] += 1;
-        }
-        if (sqrt(rsnew) < a.tol) {                                   // cg.cc:120-121: break before the p update
-            rs_prev = rsnew;
-            stop = 1;
-            break;
-        }
-        const double beta = rsnew / rsold;                           // cg.cc:124
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            p[s].x = fma(beta, p[s].x, r[s].x);                      // cg.cc:127-129
-            p[s].y = fma(beta, p[s].y, r[s].y);
-        }
-        rs_prev = rsold;
-        rsold = rsnew;                                               // cg.cc:132
-    }
-
-    // ---- state back to memory (workgroup 0; every workgroup holds the same bits)
-    if (blockIdx.x == 0) {
-#pragma unroll
-        for (int s = 0; s < S; ++s) {
-            const int c = 512 * s + 2 * tid;
-            if (ok0[s]) { a.x[c] = x[s].x; a.r[c] = r[s].x; a.p[c] = p[s].x; }
-            if (ok1[s]) { a.x[c + 1] = x[s].y; a.r[c + 1] = r[s].y; a.p[c + 1] = p[s].y; }
-        }
-        if (tid == 0) {
-            // rs[] as the per-launch path leaves it: rs[k & 1] = rsold of iteration k; on a break rs[(k+1) & 1] = rsnew
-            a.sc->rs[k & 1] = rsold;
-            a.sc->rs[(k + 1) & 1] = rs_prev;
-            if (stop) { a.sc->k_final = k; a.sc->done = 1; }
-        }
-    }
-}
-
 // ------------------------------------------------------------------------------------------------------------------------
-// 2048 < n <= 4096: the matrix (up to 128 MiB) no longer fits the LDS alone -- but a CU also has a 512 KB register file, and a
-// workgroup of 256 threads at one per CU may use all of it.  Same kernel structure, R = 16 rows per workgroup, kept in three
-// places: RL rows in LDS (as above), RG rows in REGISTERS (thread t holds its own 2 S columns of each: 4 S VGPRs per row, loaded
-// once per launch), and the remaining RS rows streamed from memory every iteration (non-temporal 16-byte loads, two rows per
-// batch, the first batch in flight while the LDS and register rows are multiplied).  S = 5: 7 + 9 + 0 (all resident, n <= 2560);
-// S = 6: 6 + 10 + 0 (all resident, n <= 3072); S = 7: 5 + 9 + 2; S = 8: 4 + 8 + 4 (n = 4096: 32 of 128 MiB re-read per iteration).
-// x is not replicated here: a workgroup keeps x for its own 16 rows only (nobody else needs it), r and p stay replicated.
+// Where a workgroup's rows live.  n <= 2048: all R <= 8 rows in LDS.  2048 < n <= 4096: the matrix (up to 128 MiB) no longer
+// fits the LDS alone -- but a CU also has a 512 KB register file, and a workgroup of 256 threads at one per CU may use all of
+// it: R = 16 rows per workgroup, RL rows in LDS, RG rows in REGISTERS (thread t holds its own 2 S columns of each: 4 S registers
+// per row, loaded once per launch), and the remaining RS rows streamed from memory every iteration (non-temporal 16-byte loads,
+// two rows per batch, the first batch of an iteration issued right behind the gather of the previous one).
+// S = 5: 7 + 9 + 0 (all resident, n <= 2560); S = 6: 6 + 10 + 0 (all resident, n <= 3072); S = 7: 5 + 9 + 2;
+// S = 8: 4 + 8 + 4 (n = 4096: 32 of 128 MiB re-read per iteration).
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int kHybR = 16;
 constexpr int hyb_rl(int S) { return (150 * 1024) / (S * 512 * 8) < kHybR ? (150 * 1024) / (S * 512 * 8) : kHybR; }
@@ -357,10 +124,14 @@ constexpr int hyb_rl(int S) { return (150 * 1024) / (S * 512 * 8) < kHybR ? (150
 constexpr int hyb_rg(int S) { return S == 5 ? 9 : S == 6 ? 10 : S == 7 ? 9 : 8; }
 #define HYB_SB 2
 
-template <int S>
-__global__ __launch_bounds__(kResThreads, 1) void k_cg_hybrid(ResidentArgs a)
+// R = rows per workgroup, a power of two (the row sums are reduced together, wave_sum_rows; the last workgroup may own fewer);
+// S = column steps of 512; RL of the rows in LDS, RG in registers, the remaining R - RL - RG streamed every iteration.
+// n <= 2048: R = 1 ... 8, RL = R (k_cg_resident<R, S, R, 0>: everything in LDS); above: R = 16 with the table above.
+template <int R, int S, int RL, int RG>
+__global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
 {
-    constexpr int R = kHybR, RL = hyb_rl(S), RG = hyb_rg(S), RS = R - RL - RG, SB = HYB_SB;
+    static_assert(RL >= 1 && RG >= 0 && RL + RG <= R, "rows in LDS + rows in registers <= rows per workgroup");
+    constexpr int RS = R - RL - RG, SB = HYB_SB;
     extern __shared__ double lds_all[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = a.n;
@@ -423,6 +194,7 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_hybrid(ResidentArgs a)
     unsigned okmask = 0;                                              // bit 2 s / 2 s + 1: column 512 s + 2 tid / + 1 is below n
     d2 xo = {0.0, 0.0};
     int sx = -1;
+    bool ox0 = false, ox1 = false;
 #pragma unroll
     for (int s = 0; s < S; ++s) {
         const int c = 512 * s + 2 * tid;
@@ -436,10 +208,14 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_hybrid(ResidentArgs a)
         } else {
             p[s] = r[s];                                              // p = r, cg.cc:85
         }
-        if (c >= row0 && c < row0 + my_rows) {                        // at most one s: the workgroup's rows span 16 columns
+        // x: only the workgroup's own rows [row0, row0 + my_rows), at most 16 columns, i.e. at most one s for a thread
+        const bool own0 = c >= row0 && c < row0 + my_rows, own1 = c + 1 >= row0 && c + 1 < row0 + my_rows;
+        if (own0 || own1) {
             sx = s;
-            xo.x = a.x[c];
-            if (c + 1 < row0 + my_rows) xo.y = a.x[c + 1];
+            ox0 = own0;
+            ox1 = own1;
+            if (own0) xo.x = a.x[c];
+            if (own1) xo.y = a.x[c + 1];
         }
     }
     double rsold, rs_prev;
@@ -648,8 +424,8 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_hybrid(ResidentArgs a)
     // ---- state back to memory: x by the workgroup that owns the rows, r / p / scalars by workgroup 0
     if (sx >= 0) {
         const int c = 512 * sx + 2 * tid;
-        a.x[c] = xo.x;
-        if (c + 1 < row0 + my_rows) a.x[c + 1] = xo.y;
+        if (ox0) a.x[c] = xo.x;
+        if (ox1) a.x[c + 1] = xo.y;
     }
     if (blockIdx.x == 0) {
 #pragma unroll
@@ -666,58 +442,48 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_hybrid(ResidentArgs a)
     }
 }
 
-// what = 0: launch; 1: prepare (raise the kernel's dynamic-LDS limit, ask the runtime how many workgroups a CU keeps resident)
-template <int R>
+// a == nullptr: prepare (raise the kernel's dynamic-LDS limit, ask the runtime how many workgroups a CU keeps resident); else launch
+template <int R, int S, int RL, int RG>
 hipError_t with_kernel(const ResidentPlan &pl, const ResidentArgs *a, hipStream_t s, int *per_cu)
 {
-    auto go = [&](auto kern) -> hipError_t {
-        if (!a) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)pl.lds_bytes);
-            if (e != hipSuccess) return e;
-            return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kern, kResThreads, pl.lds_bytes);
-        }
-        hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(kResThreads), pl.lds_bytes, s, *a);
-        return hipGetLastError();
-    };
-    switch (pl.S) {
-    case 1: return go(k_cg_resident<R, 1>);
-    case 2: return go(k_cg_resident<R, 2>);
-    case 3: return go(k_cg_resident<R, 3>);
-    case 4: return go(k_cg_resident<R, 4>);
+    auto kern = k_cg_resident<R, S, RL, RG>;
+    if (!a) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);
+        if (e != hipSuccess) return e;
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kern, kResThreads, pl.lds_bytes);
     }
-    return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(kResThreads), pl.lds_bytes, s, *a);
+    return hipGetLastError();
 }
 
-hipError_t with_hybrid(const ResidentPlan &pl, const ResidentArgs *a, hipStream_t s, int *per_cu)
+template <int R>
+hipError_t all_in_lds(const ResidentPlan &pl, const ResidentArgs *a, hipStream_t s, int *per_cu)
 {
-    auto go = [&](auto kern) -> hipError_t {
-        if (!a) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)pl.lds_bytes);
-            if (e != hipSuccess) return e;
-            return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kern, kResThreads, pl.lds_bytes);
-        }
-        hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(kResThreads), pl.lds_bytes, s, *a);
-        return hipGetLastError();
-    };
     switch (pl.S) {
-    case 5: return go(k_cg_hybrid<5>);
-    case 6: return go(k_cg_hybrid<6>);
-    case 7: return go(k_cg_hybrid<7>);
-    case 8: return go(k_cg_hybrid<8>);
+    case 1: return with_kernel<R, 1, R, 0>(pl, a, s, per_cu);
+    case 2: return with_kernel<R, 2, R, 0>(pl, a, s, per_cu);
+    case 3: return with_kernel<R, 3, R, 0>(pl, a, s, per_cu);
+    case 4: return with_kernel<R, 4, R, 0>(pl, a, s, per_cu);
     }
     return hipErrorInvalidValue;
 }
 
 hipError_t dispatch(const ResidentPlan &pl, const ResidentArgs *a, hipStream_t s, int *per_cu)
 {
-    if (pl.hybrid) return with_hybrid(pl, a, s, per_cu);
+    if (pl.hybrid) {
+        switch (pl.S) {
+        case 5: return with_kernel<kHybR, 5, hyb_rl(5), hyb_rg(5)>(pl, a, s, per_cu);
+        case 6: return with_kernel<kHybR, 6, hyb_rl(6), hyb_rg(6)>(pl, a, s, per_cu);
+        case 7: return with_kernel<kHybR, 7, hyb_rl(7), hyb_rg(7)>(pl, a, s, per_cu);
+        case 8: return with_kernel<kHybR, 8, hyb_rl(8), hyb_rg(8)>(pl, a, s, per_cu);
+        }
+        return hipErrorInvalidValue;
+    }
     switch (pl.R) {
-    case 1: return with_kernel<1>(pl, a, s, per_cu);
-    case 2: return with_kernel<2>(pl, a, s, per_cu);
-    case 4: return with_kernel<4>(pl, a, s, per_cu);
-    case 8: return with_kernel<8>(pl, a, s, per_cu);
+    case 1: return all_in_lds<1>(pl, a, s, per_cu);
+    case 2: return all_in_lds<2>(pl, a, s, per_cu);
+    case 4: return all_in_lds<4>(pl, a, s, per_cu);
+    case 8: return all_in_lds<8>(pl, a, s, per_cu);
     }
     return hipErrorInvalidValue;
 }
@@ -732,7 +498,7 @@ bool plan_resident(int n, int cus, size_t lds_per_wg, ResidentPlan *out)
     pl.S = (n + 511) / 512;
     pl.xslots = 512 * pl.S;
     if (n > 512 * 4) {
-        // 2048 < n <= 4096: 16 rows per workgroup, RL in LDS + RG in registers + RS streamed per iteration (k_cg_hybrid)
+        // 2048 < n <= 4096: 16 rows per workgroup, RL in LDS + RG in registers + RS streamed per iteration
         pl.hybrid = 1;
         pl.R = pl.rows_per_wg = kHybR;
         pl.RL = hyb_rl(pl.S);
