@@ -498,3 +498,23 @@ def test_matrix_market_input(gpu_pkg, oracle, tmp_path):
             r = s.solve(x)
         xo, ro = oracle.solve(A, b, None, 30, 0.0, 1)
         assert np.linalg.norm(x - xo) <= 1e-12 * np.linalg.norm(xo) and rel(r["residual_prev"], ro["residual_prev"]) <= 1e-10
+
+
+def test_context_life_cycles_leak_nothing(gpu_pkg):
+    """200 contexts set a resident problem, solve and go away: the device's free memory and the process's open files (the lock
+    file of the device is opened per context) are back where they were."""
+    import torch
+
+    def state():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0] / 2**20, len(os.listdir("/proc/self/fd"))
+
+    with lap(gpu_pkg, 1024, RESIDENT, 20, 0.0) as s:      # first use: the runtime's own one-time allocations
+        s.solve(np.zeros(1024))
+    mb0, fd0 = state()
+    for i in range(200):
+        n = (1024, 300, 2896)[i % 3]
+        with lap(gpu_pkg, n, RESIDENT, 5, 0.0) as s:
+            s.solve(np.zeros(n))
+    mb1, fd1 = state()
+    assert abs(mb1 - mb0) < 8 and fd1 == fd0, (mb0, mb1, fd0, fd1)
