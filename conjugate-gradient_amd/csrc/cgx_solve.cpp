@@ -471,9 +471,10 @@ cgx_status cgx_solve_end(cgx_ctx *ctx, double *x, cgx_result *res)
     // The convergence test of the last enqueued iteration is normally done by the NEXT K1; when the loop
     // ran out there is none, so close it here (cg.cc:117-121,132).
     // (the LDS-resident kernel has made that test itself; with no iteration done the state is the per-launch path's)
-    if (!ctx->resident || ctx->k == 0)
+    if (!ctx->resident || ctx->k == 0) {
         for (auto &s : ctx->shards) HIP_TRY(ctx, cgx::launch_close_iteration(s.sc, s.rv, ctx->k, ctx->tol, st));
-    CGX_TRY(read_flags_sync(ctx));
+        CGX_TRY(read_flags_sync(ctx));
+    }   // (resident: done / k_final were read behind the last launch, resident_steps; one host synchronisation less)
     const int k_exit = ctx->done ? ctx->k_final : ctx->k;
 
     // Gather x (MPI_Gatherv, cg.cc:140-142) through the exchange segments, then the DEBUG verification
