@@ -16,6 +16,9 @@
 
 #include <sys/file.h>
 
+#include <cerrno>
+#include <thread>
+
 #include <algorithm>
 #include <cctype>
 #include <chrono>
@@ -332,9 +335,19 @@ cgx_status resident_steps(cgx_ctx *ctx, int nsteps)
         a.mute_wg = ctx->res_mute_wg;
         ctx->res_mute_wg = -1;
         // one resident grid at a time on this device (setup_resident): held until the kernel has finished
+        // (bounded like every other wait of this path: a holder that never lets go -- a stopped process -- costs the
+        // serialisation after 5 s, not the solve)
         struct DeviceLock {
             int fd;
-            explicit DeviceLock(int f) : fd(f) { if (fd >= 0 && flock(fd, LOCK_EX) != 0) fd = -1; }
+            explicit DeviceLock(int f) : fd(f)
+            {
+                if (fd < 0) return;
+                const double t0 = wall_now();
+                while (flock(fd, LOCK_EX | LOCK_NB) != 0) {
+                    if (errno != EWOULDBLOCK || wall_now() - t0 > 5.0) { fd = -1; return; }
+                    std::this_thread::sleep_for(std::chrono::microseconds(50));
+                }
+            }
             ~DeviceLock() { if (fd >= 0) (void)flock(fd, LOCK_UN); }
         } lock(ctx->res_lock_fd);
         HIP_TRY(ctx, cgx::launch_cg_resident(ctx->rplan, a, ctx->stream));
