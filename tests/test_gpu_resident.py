@@ -1,5 +1,6 @@
-"""The LDS-resident solver (csrc/cgx_resident.hip: the loop code/MPI/cg.cc:95-137 as ONE persistent kernel, n <= 2048 on one
-GPU) against the oracle and against the per-launch path.  All marked gpu.
+"""The resident solver (csrc/cgx_resident.hip: the loop code/MPI/cg.cc:95-137 as ONE persistent kernel; n <= 2048: the row groups of A
+in the CUs' LDS, 2048 < n <= 4096: in LDS + registers + a streamed rest; one GPU) against the oracle and against the per-launch
+path.  All marked gpu.
 
 The rest of the GPU suite runs with CGX_RESIDENT=0 (tests/conftest.py), so that its small cases keep exercising K1 / K3;
 here the resident kernel is asked for explicitly (gemv_variant 40000) or chosen by the library's default (environment
