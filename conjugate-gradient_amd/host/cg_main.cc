@@ -406,9 +406,12 @@ int main(int argc, char **argv)
             if (stats) {
                 const cgx_result &r = solver.last_result();
                 const int it = r.iterations + (r.converged ? 1 : 0);   // loop bodies executed
+                int plan[CGX_GEMV_PLAN_INTS] = {0};
+                (void)cgx_get_gemv_plan(solver.context(), 0, plan);     // variant 4: the loop ran as one resident persistent kernel
                 std::cerr << "cgsolver stats: n=" << n << " gpus=" << psize << " loop_bodies=" << it
                           << " loop_s=" << r.seconds_loop << " iterations_per_s=" << (r.seconds_loop > 0 ? it / r.seconds_loop : 0.)
-                          << " format=" << (banded ? "banded" : "dense") << " gemv_ms_avg=" << r.gemv_ms_avg
+                          << " format=" << (banded ? "banded" : "dense")
+                          << " loop=" << (plan[0] == 4 ? "resident-kernel" : "per-launch") << " gemv_ms_avg=" << r.gemv_ms_avg
                           << " gemv_GBps_per_gpu=" << (r.gemv_ms_avg > 0 ? r.gemv_bytes / (r.gemv_ms_avg * 1e-3) / 1e9 : 0.)
                           << " hbm_roofline_frac=" << (r.gemv_ms_avg > 0 ? r.gemv_bytes / (r.gemv_ms_avg * 1e-3) / 8.0e12 : 0.)
                           << std::endl;
