@@ -94,6 +94,63 @@ __device__ __forceinline__ void stream_wait(d2 *v)
     for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i])::"memory");
 }
 
+// Sum over the 64 lanes, every lane gets it: the same pairing and order as wave_sum (lane ^ 32, lane ^ 16, then the four DPP
+// levels), so the same bits -- but the two upper levels by gfx950's v_permlane32_swap / v_permlane16_swap (VALU, a few cycles)
+// instead of ds_bpermute round trips through the LDS crossbar.  With both operands the same register x, permlane32_swap leaves
+// [x.lower | x.lower] in one result and [x.upper | x.upper] in the other: their sum is x + x(lane ^ 32) in every lane.
+__device__ __forceinline__ double wave_sum_swap(double v)
+{
+    {
+        const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
+        v = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+    }
+    {
+        const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+        v = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+    }
+    return group_sum<16>(v);
+}
+
+// a + (b of the partner half) for the first two levels of wave_sum_rows (cgx_device.h), by the same instructions: with
+// operands a = v[i], b = v[i + N/2], permlane32_swap leaves [a.lower | b.lower] and [a.upper | b.upper]; their sum is, in the
+// lower 32 lanes, own v[i] + the partner's v[i], and in the upper 32, own v[i + N/2] + the partner's v[i + N/2]: exactly what
+// the exchange "keep one half of the rows, hand the other half over" computes, without a select.  Same pairing, same bits.
+template <bool ROW16>
+__device__ __forceinline__ double swap_add(double a, double b)
+{
+    if constexpr (ROW16) {
+        const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
+        const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
+        return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+    } else {
+        const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
+        const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
+        return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+    }
+}
+
+template <int R>
+__device__ __forceinline__ int wave_sum_rows_swap(double (&v)[R], int lane)
+{
+    static_assert(R >= 1 && R <= 64 && (R & (R - 1)) == 0, "rows per workgroup must be a power of two");
+    if constexpr (R == 1) {
+        v[0] = wave_sum_swap(v[0]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < R / 2; ++i) v[i] = swap_add<false>(v[i], v[i + R / 2]);
+        if constexpr (R == 2) {
+            wave_sum_rows_step<R, 1, 16>(v, lane);
+        } else {
+#pragma unroll
+            for (int i = 0; i < R / 4; ++i) v[i] = swap_add<true>(v[i], v[i + R / 4]);
+            wave_sum_rows_step<R, R / 4, 8>(v, lane);
+        }
+    }
+    return lane / (64 / R);
+}
+
 // Where the tagged double of column c sits in a parity of the exchange buffer: inside each block of 128 columns the even ones
 // first, then the odd ones.  A thread owns the column pair (c, c + 1) (its LDS reads are 16-byte pairs of adjacent columns), so
 // with this layout the 64 lanes of a wave fetch their even columns with ONE fully coalesced 1-KiB load and their odd columns
@@ -313,7 +370,7 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
                 }
             }
         }
-        const int myrow = wave_sum_rows<R>(acc, lane);               // acc[0] = this wave's part of row `myrow`
+        const int myrow = wave_sum_rows_swap<R>(acc, lane);               // acc[0] = this wave's part of row `myrow`
         if ((lane & (64 / R - 1)) == 0) red[wave * R + myrow] = acc[0];
         __syncthreads();
         if (tid < my_rows && !(k == a.k0 && (int)blockIdx.x == a.mute_wg)) {   // (mute_wg: the test of the bounded waits)
@@ -377,7 +434,7 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
         double v = 0.0;
 #pragma unroll
         for (int s = 0; s < S; ++s) v += p[s].x * ap[s].x + p[s].y * ap[s].y;   // cg.cc:105-106
-        v = wave_sum(v);
+        v = wave_sum_swap(v);
         if (lane == 0) red[4 * R + wave] = v;
         __syncthreads();
         if (*reinterpret_cast<volatile int *>(lds_fail)) return;     // uniform: written in front of the barrier
@@ -395,7 +452,7 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
             r[s].y = fma(-alpha, ap[s].y, r[s].y);
             rr += r[s].x * r[s].x + r[s].y * r[s].y;                 // cg.cc:116
         }
-        rr = wave_sum(rr);
+        rr = wave_sum_swap(rr);
         if (lane == 0) red[4 * R + 4 + wave] = rr;
         __syncthreads();
         const double rsnew = (red[4 * R + 4] + red[4 * R + 5]) + (red[4 * R + 6] + red[4 * R + 7]);   // cg.cc:116-117
