@@ -22,7 +22,7 @@ MAX_DIAGONALS = 64
 
 EXPORTS = [
     "cgx_config_init", "cgx_comm_unique_id", "cgx_create", "cgx_destroy", "cgx_last_error", "cgx_status_string",
-    "cgx_get_comm_info", "cgx_get_gemv_plan", "cgx_p2p_export", "cgx_p2p_import", "cgx_p2p_selftest",
+    "cgx_get_comm_info", "cgx_get_gemv_plan", "cgx_get_resident_record", "cgx_p2p_export", "cgx_p2p_import", "cgx_p2p_selftest",
     "cgx_partition", "cgx_generate_lap2d_matrix", "cgx_set_matrix_dense", "cgx_read_matrix",
     "cgx_init_source_term", "cgx_set_source_term", "cgx_set_max_iter", "cgx_set_tolerance", "cgx_get_size",
     "cgx_get_matrix_format",
@@ -106,6 +106,7 @@ def lib():
         L.cgx_status_string.restype = C.c_char_p
         L.cgx_get_comm_info.argtypes = [vp, ip, ip, ip, C.c_char_p]
         L.cgx_get_gemv_plan.argtypes = [vp, C.c_int, ip]
+        L.cgx_get_resident_record.argtypes = [vp, C.POINTER(C.c_longlong)]
         L.cgx_p2p_export.argtypes = [vp, C.POINTER(C.c_ubyte)]
         L.cgx_p2p_import.argtypes = [vp, C.POINTER(C.c_ubyte)]
         L.cgx_p2p_selftest.argtypes = [vp, C.c_int, ip]
@@ -265,6 +266,13 @@ class CGSolver:
         v = (C.c_int * 8)()
         self._check(lib().cgx_get_gemv_plan(self._h, int(local_shard), v))
         return dict(zip(("variant", "R", "U", "waves", "light", "split", "grid", "ncols"), list(v)))
+
+    def resident_record(self):
+        """What the waits inside the persistent launches of the current / most recent solve cost (cgx_get_resident_record)."""
+        v = (C.c_longlong * 10)()
+        self._check(lib().cgx_get_resident_record(self._h, v))
+        return dict(zip(("iterations", "watch_repeats", "gather_repeats", "launches", "wg0_first_wait_ticks", "wg0_longest_wait_ticks",
+                         "max_first_wait_ticks", "max_longest_wait_ticks", "fallbacks", "persistent"), list(v)))
 
     # -- direct peer exchange wire-up (COMM_P2P) ------------------------------------------------------
     def p2p_export(self):

@@ -21,6 +21,9 @@ using namespace cgxi;
 
 namespace cgxi {
 
+// Largest n the DEFAULT choice hands to the streaming persistent kernel (measured against the per-launch path: DESIGN.md section 4c)
+constexpr int kStreamDefaultMax = 16384;
+
 thread_local std::string g_create_error;
 
 double wall_now()
@@ -49,8 +52,24 @@ void partition_rows(int N, int psize, int *start_rows, int *num_rows)
     num_rows[psize - 1] = N - i0;
 }
 
+void bind_state(Shard &s, long lda)
+{
+    double *b = s.state[s.cur];
+    s.x = b;
+    s.rbuf = b + cgx::state_off_r(lda);
+    s.p[1] = b + cgx::state_off_p(lda);
+    s.sc = reinterpret_cast<Scalars *>(b + cgx::state_off_sc(lda));
+    s.rv.base = s.rbuf;
+}
+
 void free_shard(Shard &s)
 {
+    if (s.state[0]) {   // x, rbuf, p[1] and sc live inside the state blocks
+        (void)hipFree(s.state[0]);
+        (void)hipFree(s.state[1]);
+        s.x = s.p[1] = s.rbuf = nullptr;
+        s.sc = nullptr;
+    }
     (void)hipFree(s.A);
     (void)hipFree(s.dia_vals);
     (void)hipFree(s.b_full);
@@ -116,23 +135,63 @@ static cgx_status scrub_tagged_region(cgx_ctx *ctx)
     return CGX_OK;
 }
 
-// The LDS-resident solver (cgx_resident.hip) takes a problem when: one GPU (CGX_COMM_SELF), dense storage, n <= 4096 (up to
-// 2048 all rows in LDS; above, 16 rows per workgroup in LDS + registers + a streamed rest), the
-// default K1 choice (gemv_variant 0; 40000 asks for it and fails if it cannot be had; any explicit per-launch shape, -1 or
-// CGX_RESIDENT=0 keep the per-launch path), and all of its workgroups are resident at once (they wait for each other).
+// One resident grid at a time per device, across contexts and processes: the workgroups of a persistent kernel wait for each
+// other, and two such grids dispatched at the same moment can each be given part of the CUs (neither fits a second workgroup beside
+// its own on a CU) and then wait for workgroups that can never be placed, until the bounded waits expire.  An advisory lock on a
+// file named after the device's PCI bus id serialises them (held from launch to the synchronisation in resident_steps; released
+// by the kernel when a process dies).  Best effort: where the file cannot be had the launches go unserialised, and a launch
+// whose waits expire is redone on the per-launch path anyway.  The file lives in /tmp because every user of the box shares the
+// device; it is only ever locked, never read or written, and it is opened defensively: never through a symbolic link
+// (O_NOFOLLOW), only a regular file with a single name (a hard link to somebody's file is refused), and the mode is widened to
+// 0666 only on a file this very call has created (O_EXCL).
+static int open_device_lock(int device)
+{
+    char bus[64] = "unknown";
+    (void)hipDeviceGetPCIBusId(bus, sizeof bus, device);
+    std::string name = std::string("/tmp/cgx_resident_") + bus + ".lock";
+    for (char &c : name)
+        if (c == ':') c = '_';
+    int fd = open(name.c_str(), O_CREAT | O_EXCL | O_RDWR | O_CLOEXEC | O_NOFOLLOW, 0666);
+    if (fd >= 0) {
+        (void)fchmod(fd, 0666);   // created here: other users of the box share the device too (the umask may have narrowed it)
+        return fd;
+    }
+    fd = open(name.c_str(), O_RDWR | O_CLOEXEC | O_NOFOLLOW);
+    if (fd < 0) fd = open(name.c_str(), O_RDONLY | O_CLOEXEC | O_NOFOLLOW);   // somebody else's file, mode narrowed: flock needs no write access
+    if (fd < 0) return -1;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_nlink != 1) {
+        close(fd);
+        return -1;
+    }
+    return fd;
+}
+
+// A persistent kernel takes a problem when: one GPU (CGX_COMM_SELF), dense storage, n <= 16384 (up to 4096 the matrix stays on
+// the chip, cgx_resident.hip: all rows in LDS up to 2048, above 16 rows per workgroup in LDS + registers + a streamed rest;
+// from 4097 every row is streamed, cgx_stream.hip), the default K1 choice (gemv_variant 0; 40000 asks for it and fails if it
+// cannot be had; any explicit per-launch shape, -1 or CGX_RESIDENT=0 keep the per-launch path; CGX_STREAM_MAX=n moves the upper
+// end of the default, 0 = never above 4096), and all of its workgroups are resident at once (they wait for each other).
 static cgx_status setup_resident(cgx_ctx *ctx, int variant)
 {
     ctx->resident = false;
-    const bool forced = variant == 40000;
+    const bool forced = variant == 40000 || variant == 50000;
+    ctx->res_forced = forced;
     if (!forced && variant != 0) return CGX_OK;
     const char *env = getenv("CGX_RESIDENT");
     if (!forced && env && atoi(env) == 0) return CGX_OK;
     auto no = [&](const char *why) {
-        return forced ? fail(ctx, CGX_ERR_UNSUPPORTED, std::string("gemv_variant 40000 (LDS-resident solver): ") + why) : CGX_OK;
+        return forced ? fail(ctx, CGX_ERR_UNSUPPORTED, std::string("gemv_variant 40000 / 50000 (persistent-kernel solver): ") + why) : CGX_OK;
     };
     if (ctx->cfg.comm_mode != CGX_COMM_SELF || ctx->banded) return no("one GPU (CGX_COMM_SELF) and dense storage only");
+    if (!forced && ctx->n > 4096) {
+        const char *smax = getenv("CGX_STREAM_MAX");
+        if (ctx->n > (smax ? atoi(smax) : kStreamDefaultMax)) return CGX_OK;
+    }
     cgx::ResidentPlan pl{};
-    if (!cgx::plan_resident(ctx->n, ctx->cus, ctx->lds_per_cu, &pl)) return no("the matrix does not fit the LDS and registers of the CUs (n <= 4096 on 256 CUs)");
+    const bool fits = variant == 50000 ? cgx::plan_stream(ctx->n, ctx->cus, ctx->lds_per_cu, &pl)   // the streaming kernel, also below 4097
+                                       : cgx::plan_resident(ctx->n, ctx->cus, ctx->lds_per_cu, &pl);
+    if (!fits) return no("the problem does not fit (n <= 16384 on 256 CUs; 50000: n >= 1024)");
     int per_cu = 0;
     if (cgx::prepare_cg_resident(pl, &per_cu) != hipSuccess) {
         (void)hipGetLastError();
@@ -141,39 +200,26 @@ static cgx_status setup_resident(cgx_ctx *ctx, int variant)
     int limit = per_cu * ctx->cus;
     if (ctx->resident_limit > 0) limit = ctx->resident_limit;
     if (pl.grid > limit) return no("its workgroups would not all be resident at once");
-    const size_t need = (size_t)2 * pl.xslots * 2 * sizeof(unsigned long long);
-    if (need > ctx->res_xbuf_bytes) {
-        (void)hipFree(ctx->res_xbuf);
-        ctx->res_xbuf = nullptr;
-        ctx->res_xbuf_bytes = 0;
-        const size_t bytes = (size_t)2 * 4096 * 2 * sizeof(unsigned long long);   // the largest plan: 128 KiB
+    if (!ctx->res_xbuf) {
+        const size_t bytes = (size_t)2 * 16384 * 2 * sizeof(unsigned long long);   // the largest plan: 512 KiB
         // ordinary device memory: the tagged words travel with agent-scope (sc1) stores and loads; fine-grained memory and
         // system scope, as between GPUs, measured the same (profiles/r04_resident/)
         HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->res_xbuf), bytes));
         ctx->res_xbuf_bytes = bytes;
     }
-    if (!ctx->d_res_err) {
-        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_res_err), sizeof(int)));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_res_err, 0, sizeof(int), ctx->stream));
+    if (!ctx->d_res_err) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_res_err), sizeof(int)));
+    if (!ctx->d_res_rec) {
+        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_res_rec), 8 * sizeof(long long)));
+        HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_res_rec), 8 * sizeof(long long), hipHostMallocDefault));
     }
-    // a freshly laid out exchange buffer holds zeros only (no tag is 0): what a reader finds in a position is then a zero or
-    // a tagged word of an earlier epoch of THIS geometry, never something another problem size left there
+    // every problem starts with the error word down (an earlier problem's expired wait must not poison this one: ADVICE r4) and
+    // with an exchange buffer of zeros only (no tag is 0): what a reader finds in a position is then a zero or a tagged word of
+    // an earlier epoch of THIS geometry, never something another problem size left there
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_res_err, 0, sizeof(int), ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->d_res_rec, 0, 8 * sizeof(long long), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->res_xbuf, 0, ctx->res_xbuf_bytes, ctx->stream));
-    if (ctx->res_lock_fd < 0 && !getenv("CGX_RESIDENT_NOLOCK")) {   // (the variable: diagnostics, to show what the lock is for)
-        // One resident grid at a time per device, across contexts and processes: its workgroups wait for each other, and two
-        // such grids dispatched at the same moment can each be given half of the CUs (neither fits a second workgroup beside
-        // its own on a CU at n = 2048) and then wait for workgroups that can never be placed, until the bounded waits expire.
-        // An advisory lock on a file named after the device's PCI bus id serialises them (held from launch to the
-        // synchronisation in resident_steps; released by the kernel when a process dies).  Best effort: where the file cannot
-        // be opened the launches go unserialised, as safe as before.
-        char bus[64] = "unknown";
-        (void)hipDeviceGetPCIBusId(bus, sizeof bus, ctx->device);
-        std::string name = std::string("/tmp/cgx_resident_") + bus + ".lock";
-        for (char &c : name)
-            if (c == ':') c = '_';
-        ctx->res_lock_fd = open(name.c_str(), O_CREAT | O_RDWR | O_CLOEXEC, 0666);
-        if (ctx->res_lock_fd >= 0) (void)fchmod(ctx->res_lock_fd, 0666);   // other users of the box share the device too
-    }
+    if (ctx->res_lock_fd < 0 && !getenv("CGX_RESIDENT_NOLOCK"))   // (the variable: diagnostics, to show what the lock is for)
+        ctx->res_lock_fd = open_device_lock(ctx->device);
     ctx->rplan = pl;
     ctx->resident = true;
     return CGX_OK;
@@ -196,6 +242,14 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
             HIP_TRY(ctx, hipMemsetAsync(s.p[1], 0, (size_t)ctx->lda * sizeof(double), ctx->stream));
             HIP_TRY(ctx, hipMemsetAsync(s.sc, 0, sizeof(Scalars), ctx->stream));
             HIP_TRY(ctx, hipMemsetAsync(s.apg, 0, (size_t)ctx->nranks * ctx->seg_S * sizeof(double), ctx->stream));
+        }
+        {   // the persistent-kernel decision is taken afresh (a problem that fell back to the per-launch path gets its chance again)
+            int variant = ctx->cfg.gemv_variant;
+            if (variant <= 0) {
+                const char *e = getenv("CGX_GEMV_VARIANT");
+                if (e) variant = atoi(e);
+            }
+            CGX_TRY(setup_resident(ctx, variant));
         }
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         return CGX_OK;
@@ -226,7 +280,7 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
     ctx->chunked = (ctx->nranks > 1 && !ctx->banded) || fused_p2p;
     const bool allow_split = ctx->chunked && !ctx->banded && ctx->nranks > 1;
     // (40000 = the LDS-resident solver, setup_resident below: set-up, verification and the probes still run the default K1)
-    const int k1_variant = variant == 40000 ? 0 : variant;
+    const int k1_variant = (variant == 40000 || variant == 50000) ? 0 : variant;
     auto plan_for = [&](int rows) {
         return ctx->banded ? cgx::plan_dia(rows, k1_variant) : cgx::plan_gemv(k1_variant, rows, ctx->n, ctx->lda, allow_split);
     };
@@ -302,14 +356,26 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
         s.npartials = 3 * cgx::update_xr_grid(n) + 8;
         if (!ctx->banded) HIP_TRY(ctx, hipMalloc(&s.A, rows_alloc * (size_t)ctx->lda * sizeof(double)));
         HIP_TRY(ctx, hipMalloc(&s.b_full, (size_t)n * sizeof(double)));
-        HIP_TRY(ctx, hipMalloc(&s.x, rows_alloc * sizeof(double)));
-        HIP_TRY(ctx, hipMalloc(&s.p[0], (size_t)ctx->lda * sizeof(double)));
-        HIP_TRY(ctx, hipMalloc(&s.p[1], (size_t)ctx->lda * sizeof(double)));
         const size_t apg_bytes = (size_t)ctx->nranks * ctx->seg_S * sizeof(double);
         const int rr_parts = cgx::update_xr_grid(n);   // one r.r partial per K3 workgroup
         const size_t rbuf_bytes = (size_t)(ctx->lda + rr_parts) * sizeof(double);
+        const bool blocks = ctx->cfg.comm_mode == CGX_COMM_SELF && !ctx->banded;   // where a persistent kernel may run the loop
+        HIP_TRY(ctx, hipMalloc(&s.p[0], (size_t)ctx->lda * sizeof(double)));
+        if (blocks) {
+            static_assert(sizeof(Scalars) <= 16 * sizeof(double), "Scalars must fit the tail of a state block");
+            const size_t bytes = (size_t)cgx::state_doubles(ctx->lda) * sizeof(double);
+            for (int q = 0; q < 2; ++q) {
+                HIP_TRY(ctx, hipMalloc(&s.state[q], bytes));
+                HIP_TRY(ctx, hipMemsetAsync(s.state[q], 0, bytes, ctx->stream));
+            }
+            s.cur = 0;
+            bind_state(s, ctx->lda);
+        } else {
+            HIP_TRY(ctx, hipMalloc(&s.x, rows_alloc * sizeof(double)));
+            HIP_TRY(ctx, hipMalloc(&s.p[1], (size_t)ctx->lda * sizeof(double)));
+            HIP_TRY(ctx, hipMalloc(&s.rbuf, rbuf_bytes));
+        }
         HIP_TRY(ctx, hipMalloc(&s.apg, apg_bytes));
-        HIP_TRY(ctx, hipMalloc(&s.rbuf, rbuf_bytes));
         s.apv = cgx::SegView{s.apg, ctx->seg_S, ctx->seg_Sr, n / ctx->nranks, ctx->nranks, n, s.rank, 0, 0, 0};
         cgx::seg_finalize(&s.apv);
         s.rv = cgx::SegView{s.rbuf, (int)ctx->lda + rr_parts, (int)ctx->lda, n, 1, n, 0, 0, 0, 0};
@@ -323,7 +389,7 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
             HIP_TRY(ctx, hipMalloc(&s.k1_scratch, (size_t)(grid_max + 8) * sizeof(double)));
             HIP_TRY(ctx, hipMemsetAsync(s.k1_scratch, 0, (size_t)(grid_max + 8) * sizeof(double), ctx->stream));
         }
-        HIP_TRY(ctx, hipMalloc(&s.sc, sizeof(Scalars)));
+        if (!blocks) HIP_TRY(ctx, hipMalloc(&s.sc, sizeof(Scalars)));
         HIP_TRY(ctx, hipMalloc(&s.gathered, (size_t)cgx::kMaxRanks * cgx::kSlots * sizeof(double)));
         HIP_TRY(ctx, hipMemsetAsync(s.p[0], 0, (size_t)ctx->lda * sizeof(double), ctx->stream));
         HIP_TRY(ctx, hipMemsetAsync(s.p[1], 0, (size_t)ctx->lda * sizeof(double), ctx->stream));
@@ -553,6 +619,11 @@ cgx_status cgx_get_gemv_plan(const cgx_ctx *ctx, int local_shard, int out[CGX_GE
 {
     if (!ctx || !out || local_shard < 0 || local_shard >= (int)ctx->shards.size()) return CGX_ERR_BAD_ARG;
     const cgx::GemvPlan &pl = ctx->shards[(size_t)local_shard].plan;
+    if (ctx->resident && ctx->rplan.stream) {   // variant 5: the loop runs as one persistent kernel that streams every row (U = column steps of 1024)
+        const int r[CGX_GEMV_PLAN_INTS] = {5, ctx->rplan.R, ctx->rplan.S, 8, ctx->rplan.RB, 1, ctx->rplan.grid, pl.ncols};   // light = rows per batch of the ring
+        memcpy(out, r, sizeof r);
+        return CGX_OK;
+    }
     if (ctx->resident) {   // variant 4: the loop runs as one persistent kernel on LDS-resident row groups (U = column steps of 512)
         // (light = rows of a workgroup held in registers: 0 up to n = 2048, where all of them are in LDS)
         const int r[CGX_GEMV_PLAN_INTS] = {4, ctx->rplan.R, ctx->rplan.S, 4, ctx->rplan.RG, 1, ctx->rplan.grid, pl.ncols};
@@ -561,6 +632,15 @@ cgx_status cgx_get_gemv_plan(const cgx_ctx *ctx, int local_shard, int out[CGX_GE
     }
     const int v[CGX_GEMV_PLAN_INTS] = {pl.variant, pl.R, pl.U, pl.waves, pl.light, pl.split, pl.grid, pl.ncols};
     memcpy(out, v, sizeof v);
+    return CGX_OK;
+}
+
+cgx_status cgx_get_resident_record(const cgx_ctx *ctx, long long out[CGX_RESIDENT_RECORD_INTS])
+{
+    if (!ctx || !out) return CGX_ERR_BAD_ARG;
+    for (int i = 0; i < 8; ++i) out[i] = ctx->res_rec[i];
+    out[8] = ctx->res_fallbacks;
+    out[9] = ctx->resident ? 1 : 0;
     return CGX_OK;
 }
 
@@ -737,6 +817,8 @@ cgx_status cgx_destroy(cgx_ctx *ctx)
     }
     (void)hipFree(ctx->res_xbuf);
     (void)hipFree(ctx->d_res_err);
+    (void)hipFree(ctx->d_res_rec);
+    if (ctx->h_res_rec) (void)hipHostFree(ctx->h_res_rec);
     if (ctx->res_lock_fd >= 0) close(ctx->res_lock_fd);
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (auto e : ctx->upd_pool) (void)hipEventDestroy(e);

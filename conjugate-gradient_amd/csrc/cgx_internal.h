@@ -24,6 +24,12 @@ struct Shard {
     double *dia_vals = nullptr;  // CGX_MATRIX_BANDED: ndiag x dia.ld, the non-zero diagonals of the row block
     cgx::DiaView dia{};
     double *b_full = nullptr;    // n doubles: b is replicated like r (the reference builds the full b on every rank, cg.cc:218-234)
+    // One GPU, dense storage (where the persistent kernels of cgx_resident.hip / cgx_stream.hip may run the loop): x, rbuf, p[1] and
+    // sc are carved out of ONE block of solver state (cgx::state_off_*), and there are two such blocks -- a persistent launch
+    // reads state[cur] and writes state[cur ^ 1], and only a launch that came back clean makes the written block the current one
+    // (bind_state).  Every other configuration allocates the four buffers one by one and state[] stays null.
+    double *state[2] = {nullptr, nullptr};
+    int cur = 0;
     double *x = nullptr;         // rows
     double *p[2] = {nullptr, nullptr};   // lda doubles each: the replicated p (cg.cc:57), ping-pong over iterations
     double *apg = nullptr;       // nranks * S doubles: exchanged segments [Ap slice | p.Ap partials] (cgx::SegView apv)
@@ -85,7 +91,7 @@ struct cgx_ctx {
                                  // run and every fused P2P update; else K1's own partials (one GPU; banded storage)
     int resident_limit = 0;      // > 0: test override of the co-residency bound of the fused P2P update (cgx_probe_set_resident_limit)
 
-    // LDS-resident solver (cgx_resident.hip): one GPU, dense, n <= 2048
+    // the persistent kernels (cgx_resident.hip: n <= 4096, A on the chip; cgx_stream.hip: n <= 16384, A streamed): one GPU, dense
     int cus = 0;                             // compute units of the device
     size_t lds_per_cu = 0;                   // LDS bytes a workgroup can be given
     bool resident = false;                   // the current problem runs the loop as one persistent kernel
@@ -96,7 +102,13 @@ struct cgx_ctx {
     int *d_res_err = nullptr;                // device word raised when a wait inside the resident kernel expired
     long long res_timeout_ticks = 0;
     int res_lock_fd = -1;                    // advisory lock file of the device: one resident grid at a time (see resident_steps)
+    bool res_lock_gave_up = false;           // a wait for that lock ran into its bound once: later launches do not wait again
     int res_mute_wg = -1;                    // test only (cgx_probe_resident_test): workgroup that skips its first publish, next launch
+    bool res_forced = false;                 // gemv_variant 40000: a launch whose waits expire is an error, not a fallback
+    long long *d_res_rec = nullptr;          // 8 x 64 bits: what the waits of the launches cost (cgx_tagged.h, resident_record)
+    long long *h_res_rec = nullptr;          // pinned: its copy, read behind every launch together with {done, k_final, error word}
+    long long res_rec[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the most recent copy (cgx_get_resident_record)
+    long long res_fallbacks = 0;             // persistent launches of this context whose waits expired and that were redone on the per-launch path
 
     // loopback pointer tables (device)
     double **d_gathered_ptrs = nullptr;
@@ -223,6 +235,7 @@ struct DeviceScratch {
 // cgx_context.cpp
 void partition_rows(int N, int psize, int *start_rows, int *num_rows);
 void free_problem(cgx_ctx *ctx);
+void bind_state(cgxi::Shard &s, long lda);     // point x / rbuf / p[1] / sc (and rv.base) into state[cur]
 long p2p_fixed_prefix(int nranks);
 cgx_status setup_problem(cgx_ctx *ctx, int n);       // allocate the shards of an n x n problem (contents: caller)
 
@@ -246,6 +259,7 @@ cgx_status gather_scalars(cgx_ctx *ctx);
 cgx_status gather_segments(cgx_ctx *ctx, bool with_tail);
 cgx_status run_gemv_plain(cgx_ctx *ctx, Shard &s, const double *v_full);
 cgx_status check_p2p_error(cgx_ctx *ctx);
+cgx_status resident_steps(cgx_ctx *ctx, int nsteps, int *redo);
 void reset_gemv_stats(cgx_ctx *ctx);
 
 }  // namespace cgxi

@@ -256,13 +256,25 @@ struct ResidentPlan {
     size_t lds_bytes;  // dynamic LDS of one workgroup
     int hybrid;        // 1 = 2048 < n <= 4096: R = 16 rows per workgroup, of which RL in LDS, RG in registers and
     int RL, RG;        //     R - RL - RG streamed from memory every iteration; 0: all R rows in LDS (RL = R, RG = 0)
+    int stream;        // 1 = cgx_stream.hip (4096 < n <= 16384): workgroups of 512 threads, S = column steps of 1024, every row
+    int RB;            //     streamed through a ring of RB rows; R = rows per workgroup (a multiple of RB), nothing kept on chip
 };
+// One block of solver state (x | r + the update kernel's r.r partials | p | Scalars), offsets in doubles from its base.  On one
+// GPU the shard keeps TWO such blocks (cgx_context.cpp): the persistent kernels read one and write the other.
+constexpr long kStateTail = 1024;   // = kMaxVectorGrid: room for one r.r partial per workgroup of the update kernel behind r
+__host__ __device__ inline long state_off_r(long lda) { return lda; }
+__host__ __device__ inline long state_off_p(long lda) { return 2 * lda + kStateTail; }
+__host__ __device__ inline long state_off_sc(long lda) { return 3 * lda + kStateTail; }
+__host__ __device__ inline long state_doubles(long lda) { return 3 * lda + kStateTail + 16; }   // Scalars: 96 bytes
 struct ResidentArgs {
     const double *A;   // n x lda, row-major, pad columns zero
     long lda;
     int n, rows_per_wg, xslots;
-    double *x, *r, *p; // n doubles each: the state between launches (p is read only when k0 > 0)
-    Scalars *sc;       // rs[], done, k_final in the per-launch path's convention
+    const double *in;  // the state the launch STARTS from, one block laid out by state_off_*: x | r | p | Scalars (p is read only
+                       // when k0 > 0; rs[] in the per-launch path's convention) -- never written: a launch whose waits expire
+                       // leaves all of it intact and the host redoes it on the per-launch path
+    double *out;       // the state the launch ENDS with, a second block of the same layout (the host makes it the current one
+                       // after a launch that came back without the error word raised): x, r, p, rs[], done, k_final
     unsigned long long *xbuf;   // device memory, 2 parities x xslots x 2 words, zero-filled when the problem is set
     unsigned long long epoch0;  // the launch uses epochs epoch0 + 1 ... epoch0 + iters
     int k0, iters;     // iterations k0 ... k0 + iters - 1 (stops at the break of cg.cc:120-121)
@@ -270,12 +282,18 @@ struct ResidentArgs {
     long long timeout_ticks;    // bound of every wait, 100 MHz wall-clock ticks
     int *err;          // device word raised when a wait expired
     int mute_wg;       // test only (cgx_probe_resident_test): this workgroup leaves out the publish of the launch's first iteration; -1 = none
+    long long *rec;    // 8 x 64 bits or nullptr: what the waits of the launch cost (resident_record, cgx_tagged.h)
     long long *prof;   // diagnostics (CGX_RESIDENT_PROFILE=1), else nullptr: workgroup 0 adds up shader-clock cycles per phase
                        // [0] GEMV + row sums + publish, [1] wait for the watched word, [2] gather, [3] p.Ap, [4] update + r.r,
                        // [5] watch rounds, [6] gather rounds, [7] iterations
 };
-// false: this problem does not fit (n > 4096, too few CUs, LDS per workgroup too small).
+// false: this problem does not fit (n > 16384, too few CUs, LDS per workgroup too small).  n <= 4096: the matrix stays on
+// the chip (cgx_resident.hip); above: every row is streamed (cgx_stream.hip, plan_stream).
 bool plan_resident(int n, int cus, size_t lds_per_wg, ResidentPlan *out);
+// The streaming persistent kernel alone (1024 <= n <= 16384; tests force it below 4096 too): plan, and prepare (a == nullptr:
+// raise the dynamic-LDS limit, *per_cu = workgroups the runtime keeps resident per CU) / launch.
+bool plan_stream(int n, int cus, size_t lds_per_wg, ResidentPlan *out);
+hipError_t stream_dispatch(const ResidentPlan &pl, const ResidentArgs *a, hipStream_t s, int *per_cu);
 // Once per plan, before the first launch: raises the kernel's dynamic-LDS limit; *workgroups_per_cu = what the runtime
 // keeps resident per CU (the caller checks grid <= that x CUs: the workgroups wait for each other).
 hipError_t prepare_cg_resident(const ResidentPlan &pl, int *workgroups_per_cu);

@@ -37,6 +37,7 @@
 // so a solve is bitwise reproducible), like every other K1 shape.  No MFMA (0.25 flop/byte), no floating-point atomics.
 #include "cgx_kernels.h"
 #include "cgx_device.h"
+#include "cgx_tagged.h"
 
 namespace cgx {
 
@@ -44,126 +45,6 @@ namespace {
 
 constexpr int kResThreads = 256;
 
-// 16-byte agent-scope load (sc1: past the L1, which no other CU's store refreshes) of one tagged double
-// {lo32, tag, hi32, tag}.  The caller waits with tagged_wait().
-__device__ __forceinline__ u4 tagged_issue(const unsigned long long *src)
-{
-    u4 w;
-    asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(w) : "v"(src) : "memory");
-    return w;
-}
-
-// One double as two tagged words, ONE 16-byte agent-scope write-through store (between GPUs the same words travel at system
-// scope: tagged_store in cgx_device.h).
-__device__ __forceinline__ void tagged_put(unsigned long long *dst, double v, unsigned tag)
-{
-    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
-    const u4 w = {(unsigned)bits, tag, (unsigned)(bits >> 32), tag};
-    asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(dst), "v"(w) : "memory");
-}
-
-template <int S>
-__device__ __forceinline__ void tagged_wait(u4 (&w)[2 * S])
-{
-    // the loaded registers are operands of the wait, so that no use of them can be scheduled in front of it
-    if constexpr (S == 1) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1])::"memory");
-    if constexpr (S == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3])::"memory");
-    if constexpr (S == 3)
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5])::"memory");
-    if constexpr (S == 4)
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7])::"memory");
-    if constexpr (S > 4) {   // (an asm statement takes at most 30 operands)
-        asm volatile("s_waitcnt vmcnt(0)"
-                     : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7])::"memory");
-        if constexpr (S == 5) asm volatile("" : "+v"(w[8]), "+v"(w[9])::"memory");
-        if constexpr (S == 6) asm volatile("" : "+v"(w[8]), "+v"(w[9]), "+v"(w[10]), "+v"(w[11])::"memory");
-        if constexpr (S == 7) asm volatile("" : "+v"(w[8]), "+v"(w[9]), "+v"(w[10]), "+v"(w[11]), "+v"(w[12]), "+v"(w[13])::"memory");
-        if constexpr (S == 8)
-            asm volatile("" : "+v"(w[8]), "+v"(w[9]), "+v"(w[10]), "+v"(w[11]), "+v"(w[12]), "+v"(w[13]), "+v"(w[14]), "+v"(w[15])::"memory");
-    }
-}
-
-// wait for the N 16-byte loads of a batch of streamed rows (the registers are operands, as in tagged_wait)
-template <int N>
-__device__ __forceinline__ void stream_wait(d2 *v)
-{
-    static_assert(N >= 1 && N <= 16, "a batch of streamed rows is at most 16 loads");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(v[i])::"memory");
-}
-
-// Sum over the 64 lanes, every lane gets it: the same pairing and order as wave_sum (lane ^ 32, lane ^ 16, then the four DPP
-// levels), so the same bits -- but the two upper levels by gfx950's v_permlane32_swap / v_permlane16_swap (VALU, a few cycles)
-// instead of ds_bpermute round trips through the LDS crossbar.  With both operands the same register x, permlane32_swap leaves
-// [x.lower | x.lower] in one result and [x.upper | x.upper] in the other: their sum is x + x(lane ^ 32) in every lane.
-__device__ __forceinline__ double wave_sum_swap(double v)
-{
-    {
-        const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(v), __double2loint(v), false, false);
-        const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(v), __double2hiint(v), false, false);
-        v = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
-    }
-    {
-        const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
-        const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
-        v = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
-    }
-    return group_sum<16>(v);
-}
-
-// a + (b of the partner half) for the first two levels of wave_sum_rows (cgx_device.h), by the same instructions: with
-// operands a = v[i], b = v[i + N/2], permlane32_swap leaves [a.lower | b.lower] and [a.upper | b.upper]; their sum is, in the
-// lower 32 lanes, own v[i] + the partner's v[i], and in the upper 32, own v[i + N/2] + the partner's v[i + N/2]: exactly what
-// the exchange "keep one half of the rows, hand the other half over" computes, without a select.  Same pairing, same bits.
-template <bool ROW16>
-__device__ __forceinline__ double swap_add(double a, double b)
-{
-    if constexpr (ROW16) {
-        const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(a), __double2loint(b), false, false);
-        const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(a), __double2hiint(b), false, false);
-        return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
-    } else {
-        const auto lo = __builtin_amdgcn_permlane32_swap(__double2loint(a), __double2loint(b), false, false);
-        const auto hi = __builtin_amdgcn_permlane32_swap(__double2hiint(a), __double2hiint(b), false, false);
-        return __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
-    }
-}
-
-template <int R>
-__device__ __forceinline__ int wave_sum_rows_swap(double (&v)[R], int lane)
-{
-    static_assert(R >= 1 && R <= 64 && (R & (R - 1)) == 0, "rows per workgroup must be a power of two");
-    if constexpr (R == 1) {
-        v[0] = wave_sum_swap(v[0]);
-    } else {
-#pragma unroll
-        for (int i = 0; i < R / 2; ++i) v[i] = swap_add<false>(v[i], v[i + R / 2]);
-        if constexpr (R == 2) {
-            wave_sum_rows_step<R, 1, 16>(v, lane);
-        } else {
-#pragma unroll
-            for (int i = 0; i < R / 4; ++i) v[i] = swap_add<true>(v[i], v[i + R / 4]);
-            wave_sum_rows_step<R, R / 4, 8>(v, lane);
-        }
-    }
-    return lane / (64 / R);
-}
-
-// Where the tagged double of column c sits in a parity of the exchange buffer: inside each block of 128 columns the even ones
-// first, then the odd ones.  A thread owns the column pair (c, c + 1) (its LDS reads are 16-byte pairs of adjacent columns), so
-// with this layout the 64 lanes of a wave fetch their even columns with ONE fully coalesced 1-KiB load and their odd columns
-// with another, instead of two loads that each touch half of 16 lines.
-__device__ __forceinline__ int xpos(int c)
-{
-    return (c & ~127) | ((c & 1) << 6) | ((c & 127) >> 1);
-}
-
-__device__ __forceinline__ double tagged_value(const u4 &w)
-{
-    return __longlong_as_double((long long)((unsigned long long)w.x | ((unsigned long long)w.z << 32)));
-}
 
 // ------------------------------------------------------------------------------------------------------------------------
 // Where a workgroup's rows live.  n <= 2048: all R <= 8 rows in LDS.  2048 < n <= 4096: the matrix (up to 128 MiB) no longer
@@ -247,6 +128,8 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
     }
 
     // ---- state: r, p for this thread's columns (replicated in every workgroup); x for the workgroup's own rows only
+    const double *st_x = a.in, *st_r = a.in + state_off_r(a.lda), *st_p = a.in + state_off_p(a.lda);
+    const Scalars *st_sc = reinterpret_cast<const Scalars *>(a.in + state_off_sc(a.lda));
     d2 r[S], p[S];
     unsigned okmask = 0;                                              // bit 2 s / 2 s + 1: column 512 s + 2 tid / + 1 is below n
     d2 xo = {0.0, 0.0};
@@ -257,11 +140,11 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
         const int c = 512 * s + 2 * tid;
         const bool ok0 = c < n, ok1 = c + 1 < n;
         okmask |= (ok0 ? 1u : 0u) << (2 * s) | (ok1 ? 1u : 0u) << (2 * s + 1);
-        r[s].x = ok0 ? a.r[c] : 0.0;
-        r[s].y = ok1 ? a.r[c + 1] : 0.0;
+        r[s].x = ok0 ? st_r[c] : 0.0;
+        r[s].y = ok1 ? st_r[c + 1] : 0.0;
         if (a.k0 > 0) {
-            p[s].x = ok0 ? a.p[c] : 0.0;
-            p[s].y = ok1 ? a.p[c + 1] : 0.0;
+            p[s].x = ok0 ? st_p[c] : 0.0;
+            p[s].y = ok1 ? st_p[c + 1] : 0.0;
         } else {
             p[s] = r[s];                                              // p = r, cg.cc:85
         }
@@ -271,14 +154,14 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
             sx = s;
             ox0 = own0;
             ox1 = own1;
-            if (own0) xo.x = a.x[c];
-            if (own1) xo.y = a.x[c + 1];
+            if (own0) xo.x = st_x[c];
+            if (own1) xo.y = st_x[c + 1];
         }
     }
     double rsold, rs_prev;
     if (a.k0 > 0) {
-        rsold = a.sc->rs[a.k0 & 1];
-        rs_prev = a.sc->rs[(a.k0 + 1) & 1];
+        rsold = st_sc->rs[a.k0 & 1];
+        rs_prev = st_sc->rs[(a.k0 + 1) & 1];
     } else {
         double v = 0.0;
 #pragma unroll
@@ -305,6 +188,9 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
     int k = a.k0, stop = 0;
     const int k_end = a.k0 + a.iters;
     unsigned long long epoch = a.epoch0;
+    // what this workgroup's waits cost (a.rec): thread 0 keeps it in four LDS words (the kernel has no register to spare)
+    unsigned *lds_rec = reinterpret_cast<unsigned *>(lds_fail) + 2;   // [watch rounds | repeated gather rounds | first wait | longest later wait]
+    if (tid < 4) lds_rec[tid] = 0;
     for (; k < k_end; ++k) {
         ++epoch;
         const unsigned tag = p2p_tag(epoch);
@@ -423,6 +309,13 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
                 any = need != 0;
                 if (any && wall_clock64() - t0 > a.timeout_ticks) expired = true;
             }
+            // what the exchange of this iteration cost, kept only when it took more than one round trip per phase (or for the
+            // launch's first iteration, where a workgroup that was placed late shows): a.rec, resident_record
+            if (tid == 0 && (watch_rounds + gather_rounds > 2 || k == a.k0)) {
+                atomicAdd(lds_rec, (unsigned)(watch_rounds - 1));
+                atomicAdd(lds_rec + 1, (unsigned)(gather_rounds - 1));
+                atomicMax(lds_rec + (k == a.k0 ? 2 : 3), (unsigned)(wall_clock64() - t0));
+            }
             if (expired) {
                 atomicExch(a.err, 1);
                 *reinterpret_cast<volatile int *>(lds_fail) = 1;
@@ -479,24 +372,30 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
     }
 
     // ---- state back to memory: x by the workgroup that owns the rows, r / p / scalars by workgroup 0
+    // (into the OUTPUT set: the state the launch started from stays intact, so that a launch whose waits expired can be redone
+    // on the per-launch path, resident_steps in cgx_solve.cpp)
     if (sx >= 0) {
         const int c = 512 * sx + 2 * tid;
-        if (ox0) a.x[c] = xo.x;
-        if (ox1) a.x[c + 1] = xo.y;
+        if (ox0) a.out[c] = xo.x;
+        if (ox1) a.out[c + 1] = xo.y;
     }
     if (blockIdx.x == 0) {
+        double *r_out = a.out + state_off_r(a.lda), *p_out = a.out + state_off_p(a.lda);
+        Scalars *sc_out = reinterpret_cast<Scalars *>(a.out + state_off_sc(a.lda));
 #pragma unroll
         for (int s = 0; s < S; ++s) {
             const int c = 512 * s + 2 * tid;
-            if ((okmask >> (2 * s)) & 1u) { a.r[c] = r[s].x; a.p[c] = p[s].x; }
-            if ((okmask >> (2 * s + 1)) & 1u) { a.r[c + 1] = r[s].y; a.p[c + 1] = p[s].y; }
+            if ((okmask >> (2 * s)) & 1u) { r_out[c] = r[s].x; p_out[c] = p[s].x; }
+            if ((okmask >> (2 * s + 1)) & 1u) { r_out[c + 1] = r[s].y; p_out[c + 1] = p[s].y; }
         }
         if (tid == 0) {
-            a.sc->rs[k & 1] = rsold;
-            a.sc->rs[(k + 1) & 1] = rs_prev;
-            if (stop) { a.sc->k_final = k; a.sc->done = 1; }
+            sc_out->rs[k & 1] = rsold;
+            sc_out->rs[(k + 1) & 1] = rs_prev;
+            sc_out->k_final = stop ? k : 0;
+            sc_out->done = stop;
         }
     }
+    if (tid == 0 && a.rec) resident_record(a.rec, blockIdx.x == 0, k - a.k0 + stop, lds_rec[0], lds_rec[1], lds_rec[2], lds_rec[3]);
 }
 
 // a == nullptr: prepare (raise the kernel's dynamic-LDS limit, ask the runtime how many workgroups a CU keeps resident); else launch
@@ -527,6 +426,7 @@ hipError_t all_in_lds(const ResidentPlan &pl, const ResidentArgs *a, hipStream_t
 
 hipError_t dispatch(const ResidentPlan &pl, const ResidentArgs *a, hipStream_t s, int *per_cu)
 {
+    if (pl.stream) return stream_dispatch(pl, a, s, per_cu);
     if (pl.hybrid) {
         switch (pl.S) {
         case 5: return with_kernel<kHybR, 5, hyb_rl(5), hyb_rg(5)>(pl, a, s, per_cu);
@@ -550,7 +450,8 @@ hipError_t dispatch(const ResidentPlan &pl, const ResidentArgs *a, hipStream_t s
 bool plan_resident(int n, int cus, size_t lds_per_wg, ResidentPlan *out)
 {
     ResidentPlan pl{};
-    if (n < 1 || n > 512 * 8 || cus < 1) return false;
+    if (n > 512 * 8) return plan_stream(n, cus, lds_per_wg, out);
+    if (n < 1 || cus < 1) return false;
     const int G = cus < 256 ? cus : 256;
     pl.S = (n + 511) / 512;
     pl.xslots = 512 * pl.S;

@@ -296,75 +296,143 @@ cgx_status read_flags_sync(cgx_ctx *ctx)
     return CGX_OK;
 }
 
-// The loop cg.cc:95-137 as launches of the LDS-resident persistent kernel (cgx_resident.hip): up to kResidentBatch
-// iterations per launch (a launch of a non-converging solve stays bounded), state (x, r, p, rs[], done, k_final) in HBM in
-// between.  The break of cg.cc:120-121 is taken inside the kernel, at the iteration the reference takes it.
+// The loop cg.cc:95-137 as launches of a persistent kernel (cgx_resident.hip: A on the chip; cgx_stream.hip: A streamed): up
+// to kResidentBatch iterations per launch (a launch of a non-converging solve stays bounded).  Between launches the state
+// (x, r, p, rs[], done, k_final) lies in HBM in one of the shard's two state blocks; a launch reads state[cur] and writes the
+// other block, which becomes the current one only when the launch came back with the error word down.  The break of
+// cg.cc:120-121 is taken inside the kernel, at the iteration the reference takes it.
 constexpr int kResidentBatch = 1 << 16;
 
-cgx_status resident_steps(cgx_ctx *ctx, int nsteps)
+namespace {
+
+// one persistent grid at a time on this device (open_device_lock in cgx_context.cpp): held until the kernel has finished.
+// Bounded like every other wait of this path: a holder that never lets go -- a stopped process, somebody's flock on the
+// world-writable file -- costs the serialisation after 5 s, ONCE per context, not the solve.
+struct DeviceLock {
+    int fd;
+    explicit DeviceLock(cgx_ctx *ctx) : fd(ctx->res_lock_gave_up ? -1 : ctx->res_lock_fd)
+    {
+        if (fd < 0) return;
+        const double t0 = wall_now();
+        while (flock(fd, LOCK_EX | LOCK_NB) != 0) {
+            if (errno != EWOULDBLOCK || wall_now() - t0 > 5.0) {
+                ctx->res_lock_gave_up = true;
+                fd = -1;
+                return;
+            }
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+    }
+    // (an early return through HIP_TRY has drained the stream first -- quiesce() -- so the grid is gone when the lock is)
+    ~DeviceLock() { if (fd >= 0) (void)flock(fd, LOCK_UN); }
+};
+
+}  // namespace
+
+// *redo = 0: all of nsteps (or up to the break) ran in persistent launches.  *redo > 0: a wait inside a launch expired (its
+// workgroups were not all resident at once: another tenant of the GPU, a CU mask); the state that launch started from is
+// intact, the context has left the persistent path for the rest of this problem, the iteration in flight between the two
+// conventions has been enqueued, and *redo iterations remain for the per-launch loop of cgx_solve_steps.
+cgx_status resident_steps(cgx_ctx *ctx, int nsteps, int *redo)
 {
     Shard &s = ctx->shards[0];
+    *redo = 0;
     int left = std::min(nsteps, ctx->max_iter - ctx->k);
     // diagnostics: CGX_RESIDENT_PROFILE=1 prints where workgroup 0 spent its cycles (per steps call, on stderr)
     DeviceScratch scratch;
     long long *d_prof = nullptr;
+    constexpr int kProfWords = 8 + 4 * 256 * 4;   // 8 phase counters (cgx_resident.hip) + 4 stamps per workgroup (cgx_stream.hip)
     if (getenv("CGX_RESIDENT_PROFILE")) {
-        HIP_TRY(ctx, scratch.alloc(&d_prof, 8 * sizeof(long long)));
-        HIP_TRY(ctx, hipMemsetAsync(d_prof, 0, 8 * sizeof(long long), ctx->stream));
+        HIP_TRY(ctx, scratch.alloc(&d_prof, kProfWords * sizeof(long long)));
+        HIP_TRY(ctx, hipMemsetAsync(d_prof, 0, kProfWords * sizeof(long long), ctx->stream));
     }
     while (left > 0 && !ctx->done) {
         const int batch = std::min(left, kResidentBatch);
+        const int k0 = ctx->k;
         cgx::ResidentArgs a{};
         a.A = s.A;
         a.lda = ctx->lda;
         a.n = ctx->n;
         a.rows_per_wg = ctx->rplan.rows_per_wg;
         a.xslots = ctx->rplan.xslots;
-        a.x = s.x;
-        a.r = s.rv.base;
-        a.p = s.p[1];
-        a.sc = s.sc;
+        a.in = s.state[s.cur];
+        a.out = s.state[s.cur ^ 1];
         a.xbuf = ctx->res_xbuf;
         a.epoch0 = ctx->res_epoch;
-        a.k0 = ctx->k;
+        a.k0 = k0;
         a.iters = batch;
         a.tol = ctx->tol;
         a.timeout_ticks = ctx->res_timeout_ticks;
         a.err = ctx->d_res_err;
+        a.rec = ctx->d_res_rec;
         a.prof = d_prof;
         a.mute_wg = ctx->res_mute_wg;
         ctx->res_mute_wg = -1;
-        // one resident grid at a time on this device (setup_resident): held until the kernel has finished
-        // (bounded like every other wait of this path: a holder that never lets go -- a stopped process -- costs the
-        // serialisation after 5 s, not the solve)
-        struct DeviceLock {
-            int fd;
-            explicit DeviceLock(int f) : fd(f)
-            {
-                if (fd < 0) return;
-                const double t0 = wall_now();
-                while (flock(fd, LOCK_EX | LOCK_NB) != 0) {
-                    if (errno != EWOULDBLOCK || wall_now() - t0 > 5.0) { fd = -1; return; }
-                    std::this_thread::sleep_for(std::chrono::microseconds(50));
-                }
-            }
-            ~DeviceLock() { if (fd >= 0) (void)flock(fd, LOCK_UN); }
-        } lock(ctx->res_lock_fd);
-        HIP_TRY(ctx, cgx::launch_cg_resident(ctx->rplan, a, ctx->stream));
-        ctx->res_epoch += (unsigned long long)batch;
-        ctx->k += batch;
-        left -= batch;
         int *flags = ctx->h_flags + 4;
-        flags[2] = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(flags, &s.sc->done, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipMemcpyAsync(flags + 2, ctx->d_res_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        {
+            DeviceLock lock(ctx);
+            HIP_TRY(ctx, cgx::launch_cg_resident(ctx->rplan, a, ctx->stream));
+            flags[2] = 0;
+            const cgx::Scalars *sc_out = reinterpret_cast<const cgx::Scalars *>(a.out + cgx::state_off_sc(ctx->lda));
+            HIP_TRY(ctx, hipMemcpyAsync(flags, &sc_out->done, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(flags + 2, ctx->d_res_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_res_rec, ctx->d_res_rec, 8 * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        }
+        memcpy(ctx->res_rec, ctx->h_res_rec, sizeof ctx->res_rec);
+        if (flags[2]) {
+            // A wait for another workgroup's Ap expired: the grid was not resident at once.  Epochs that may have been used:
+            ctx->res_epoch += (unsigned long long)batch;
+            if (ctx->res_forced)
+                return fail(ctx, CGX_ERR_HIP, "persistent-kernel solver (gemv_variant 40000): a wait for another workgroup's Ap expired (the "
+                                              "grid was not resident at once?)");
+            // The default choice has a way out: the launch wrote only the OTHER state block, so the state it
+            // started from is intact; put the error word down, forget whatever tagged words the launch left, and go on -- from
+            // iteration k0 -- on the per-launch path, for the rest of this problem.
+            HIP_TRY(ctx, hipMemsetAsync(ctx->d_res_err, 0, sizeof(int), ctx->stream));
+            HIP_TRY(ctx, hipMemsetAsync(ctx->res_xbuf, 0, ctx->res_xbuf_bytes, ctx->stream));
+            ctx->resident = false;
+            ctx->res_fallbacks++;
+            ctx->err = "note: a persistent launch could not keep its workgroups resident at once; the solve continued on the per-launch path";
+            if (k0 > 0) {
+                // Between launches the persistent kernels leave p ALREADY formed (p_k0 in p[1], rs[k0 & 1] = rsold), where the
+                // per-launch K1 of iteration k0 would form it from p_(k0-1) itself.  So iteration k0 runs as: the plain K1 on the
+                // formed p (Ap and the p.Ap partials, no head), then K3 as ever; from k0 + 1 on the fused K1 finds what it expects:
+                // p_old = p_k0 in p[(k0 + 1) & 1], K3's r.r partials behind r, rsold in rs[k0 & 1].
+                double *pk = s.p[(k0 + 1) & 1];
+                if (pk != s.p[1]) HIP_TRY(ctx, hipMemcpyAsync(pk, s.p[1], (size_t)ctx->lda * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+                CGX_TRY(run_gemv_plain(ctx, s, pk));
+                HIP_TRY(ctx, cgx::launch_update_xr(ctx->n, s.rows, s.row0, pk, s.apv, 0, ctx->npart, s.x, s.rv, s.sc, k0 & 1, s.partials,
+                                                   ctx->stream));                                   // cg.cc:105-116
+                ctx->k = k0 + 1;
+                --left;
+            }
+            *redo = left;
+            return CGX_OK;
+        }
         ctx->done = flags[0] != 0;
         ctx->k_final = flags[1];
-        if (flags[2])
-            return fail(ctx, CGX_ERR_HIP, "LDS-resident solver: a wait for another workgroup's Ap expired (the grid was not resident at once?)");
+        // (epochs used: one per iteration that ran -- up to and including the one that took the break)
+        ctx->res_epoch += (unsigned long long)(ctx->done ? ctx->k_final - k0 + 1 : batch);
+        ctx->k += batch;
+        left -= batch;
+        s.cur ^= 1;                 // the block the launch wrote is the state now
+        bind_state(s, ctx->lda);
     }
-    if (d_prof) {
+    if (d_prof && ctx->rplan.stream) {
+        // one line per workgroup for the stamped iteration: xcd, begin of its sweep, row sums done, Ap gathered (us after the earliest begin)
+        std::vector<long long> h(kProfWords);
+        HIP_TRY(ctx, hipMemcpy(h.data(), d_prof, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+        for (int j = 0; j < 4; ++j) {
+            const long long *hj = h.data() + 8 + 4 * 256 * j;
+            long long t0 = 0;
+            for (int g = 0; g < ctx->rplan.grid; ++g)
+                if (hj[4 * g] && (!t0 || hj[4 * g] < t0)) t0 = hj[4 * g];
+            for (int g = 0; g < ctx->rplan.grid && t0; ++g)
+                fprintf(stderr, "cgx stream profile: n=%d sample=%d wg=%d xcd=%lld begin=%.2f sums=%.2f gathered=%.2f\n", ctx->n, j, g, hj[4 * g + 3],
+                        (hj[4 * g] - t0) / 100.0, (hj[4 * g + 1] - t0) / 100.0, (hj[4 * g + 2] - t0) / 100.0);
+        }
+    } else if (d_prof) {
         long long h[8];
         HIP_TRY(ctx, hipMemcpy(h, d_prof, sizeof h, hipMemcpyDeviceToHost));
         const double it = h[7] > 0 ? (double)h[7] : 1.0;
@@ -418,6 +486,12 @@ cgx_status cgx_solve_begin(cgx_ctx *ctx, const double *x0)
         HIP_TRY(ctx, hipMemsetAsync(s.p[0], 0, vec_bytes, st));
         HIP_TRY(ctx, hipMemsetAsync(s.p[1], 0, vec_bytes, st));
     }
+    if (ctx->resident) {
+        // a solve starts with the error word down and an empty record of what its waits cost
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_res_err, 0, sizeof(int), st));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->d_res_rec, 0, 8 * sizeof(long long), st));
+        memset(ctx->res_rec, 0, sizeof ctx->res_rec);
+    }
     ctx->in_solve = true;
     return CGX_OK;
 }
@@ -430,10 +504,14 @@ cgx_status cgx_solve_steps(cgx_ctx *ctx, int nsteps, int *done_out)
     // K1 statistics describe the most recent steps call (bench.py: the timed region, not the warmup)
     reset_gemv_stats(ctx);
     if (ctx->resident) {
-        CGX_TRY(resident_steps(ctx, nsteps));
-        ctx->t_loop += wall_now() - t0;
-        if (done_out) *done_out = ctx->done ? 1 : 0;
-        return CGX_OK;
+        int redo = 0;
+        CGX_TRY(resident_steps(ctx, nsteps, &redo));
+        if (redo == 0) {
+            ctx->t_loop += wall_now() - t0;
+            if (done_out) *done_out = ctx->done ? 1 : 0;
+            return CGX_OK;
+        }
+        nsteps = redo;   // a persistent launch's waits expired: the rest of the call runs below, on the per-launch path
     }
     bool window_open = false;   // the start marker of THIS call is on the stream (a stop marker is only paired with that)
     if (ctx->cfg.profile_gemv && nsteps > 0 && !ctx->done) {

@@ -1,0 +1,442 @@
+// cgx_stream.hip -- the whole CG loop of code/MPI/cg.cc:95-137 as ONE persistent kernel for matrices that do NOT fit on the chip:
+// 4096 < n <= 16384 on one GPU (BASELINE config 2, N = 10000; the reference's largest published size, N = 8192,
+// results/strong_scaling.txt:22).
+//
+// There the per-launch path streams A at the rate the memory system gives (K1 at 0.89-0.91 of 8 TB/s, profiles/r05_midsize/),
+// and what an iteration loses is everything around K1: the update kernel K3 (4.8-5.0 us of latency chain), two kernel
+// boundaries and two launch ramps -- 6-7 % of an 80 us iteration at N = 8192.  This kernel keeps cgx_resident.hip's structure
+// (r and p replicated in every workgroup, Ap exchanged as tagged words, no K3, no kernel boundary, no grid barrier) and
+// streams ALL rows:
+//
+//   grid  = G <= 256 workgroups of 512 threads (8 waves, 2 per SIMD, up to 256 registers each), one per CU, all resident;
+//           workgroup g owns the R = ceil(n / 256) (rounded up to the batch) consecutive rows g R ... g R + R - 1;
+//   state = r, p in registers, replicated in every workgroup: thread t owns the column pairs {1024 s + 2 t, + 1}, s < S =
+//           ceil(n / 1024) -- the same columns whose entries of A it streams, so the GEMV needs no vector traffic at all;
+//   A     = streamed through a RING of RB x S 16-byte registers per thread (RB rows of the thread's columns): a slot is
+//           consumed (two FMAs) and at once re-issued for the row RB further on -- non-temporal BUFFER loads (descriptor of the
+//           workgroup's row block in SGPRs, row and column step as a scalar offset, the thread's position ONE 32-bit register
+//           for all of them; rows and columns outside the block read as 0 by the range check), issued through the compiler's
+//           builtins, so every wait on streamed data is the compiler's own vmcnt bookkeeping (no hand-written waits: ADVICE r4).  The rows do not depend on p, so the ring simply
+//           wraps around: while the workgroups exchange Ap and update r and p, the first RB rows of the NEXT iteration are
+//           already in flight (128 KB per CU at N = 8192) and the memory pipe does not run dry across the iteration boundary;
+//   one iteration (cg.cc:96-137) =
+//     Ap_sub = A_sub p            every wave sweeps its 128 columns of each 1024-column step of every row; per batch of RB rows
+//                                 one wave reduction (v_permlane swaps + DPP), per row 8 wave partials in LDS    cg.cc:100-102
+//     publish Ap_sub              R tagged doubles per workgroup (cgx_tagged.h)
+//     gather Ap                   every thread polls one watched word, then the tagged words of its 2 S columns in chunks of
+//                                 <= 8 (agent-scope buffer loads: one 32-bit lane offset, parity and column step scalar)
+//     p.Ap, alpha, x, r, r.r, break test, beta, p: as cgx_resident.hip, every workgroup over the whole vectors, same order:
+//                                 bit-identical everywhere                                                         cg.cc:105-132
+//
+// The barriers inside an iteration hand over LDS words only and are `s_waitcnt lgkmcnt(0); s_barrier` (lds_barrier):
+// __syncthreads() would wait for vmcnt(0), i.e. for the prefetched rows of the next iteration, in front of every publish.
+// State between launches, waits bounded by the wall clock, error word, test hooks: exactly cgx_resident.hip's (same
+// ResidentArgs), so the host code (resident_steps, cgx_solve.cpp) is the same for both kernels.
+// The arithmetic per element is the reference's; only the summation order of the dot products is this kernel's own (fixed,
+// so a solve is bitwise reproducible).  No MFMA (0.25 flop/byte), no floating-point atomics.
+#include "cgx_kernels.h"
+#include "cgx_device.h"
+#include "cgx_tagged.h"
+
+namespace cgx {
+
+namespace {
+
+constexpr int kStrThreads = 512, kStrWaves = 8;
+
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr int kAuxNt = 2;                        // nt: streamed once, do not keep
+constexpr int kAuxSc1 = 16;                      // sc1: agent scope (loads past the L1, stores written through)
+// (a poll is an sc1 load as well; what makes the compiler re-issue it every time round a loop is the `asm volatile("" ::: "memory")`
+// in front of it -- the intrinsic's own volatile bit would turn it into a system-scope sc0 sc1 load)
+
+__device__ __forceinline__ d2 as_d2(u4 w) { return __builtin_bit_cast(d2, w); }
+__device__ __forceinline__ bool tag_ok(const u4 &w, unsigned tag) { return ((w.y ^ tag) | (w.w ^ tag)) == 0; }
+
+// v + v(lane ^ 16) and so on down to groups of 1: the sum over each half wave, every lane of the half gets it; the 16-lane
+// level by v_permlane16_swap (VALU) instead of a ds_bpermute round trip (same pairing as group_sum<32>, same bits)
+__device__ __forceinline__ double half_wave_sum_swap(double v)
+{
+    const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
+    v = __hiloint2double(hi[0], lo[0]) + __hiloint2double(hi[1], lo[1]);
+    return group_sum<16>(v);
+}
+
+// the row sums of a batch over the wave: afterwards v[0] of lane L is the total of row L / (64 / RB)
+template <int RB>
+__device__ __forceinline__ int batch_sum(double (&v)[RB], int lane)
+{
+    if constexpr (RB == 2) {
+        v[0] = half_wave_sum_swap(swap_add<false>(v[0], v[1]));
+        return lane >> 5;
+    } else {
+        return wave_sum_rows_swap<RB>(v, lane);
+    }
+}
+
+// S = column steps of 1024 (n <= 1024 S); RB = rows per batch = depth of the ring in rows (a power of two: the batch's row
+// sums are reduced together); CH = column steps per gather chunk (2 CH tagged words in flight per thread).
+// Registers (hipcc 7.2, tools/kernel_resources.py): p and r 8 S, the ring 4 RB S, a gather chunk 8 CH; the gathered Ap is
+// parked in LDS between p.Ap and the update of r (8 KB per column step), so it costs none.
+template <int S, int RB, int CH>
+__global__ __launch_bounds__(kStrThreads, 2) void k_cg_stream(ResidentArgs a)
+{
+    constexpr int T = kStrThreads, W = kStrWaves;
+    extern __shared__ double lds_all[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = a.n, R = a.rows_per_wg, nb = R / RB;
+    double *lds_red = lds_all;                        // [W][R]: the waves' parts of the row sums
+    double *lds_dot = lds_red + W * R;                // two sets of [p.Ap | r.r] x W wave partials
+    double *lds_sum = lds_dot + 4 * W;                // W doubles for the set-up's block sum
+    // one word: a wait of this workgroup expired (+ pad).  Plain LDS accesses, ordered by the barriers: a `volatile` access through a
+    // cast pointer becomes a FLAT instruction, and with one of those pending the compiler turns every later wait into vmcnt(0)
+    int *lds_fail = reinterpret_cast<int *>(lds_sum + W);
+    unsigned *lds_rec = reinterpret_cast<unsigned *>(lds_fail) + 2;   // thread 0: [watch rounds | repeated gather rounds | first wait | longest later wait] (a.rec)
+    d2 *lds_ap = reinterpret_cast<d2 *>(lds_sum + W + 4);   // [S][T] pairs: the gathered Ap of this thread's columns
+    const int row0 = blockIdx.x * R;
+    const int my_rows = min(R, n - row0);             // >= 1 by construction of the grid
+
+    if (tid == 0) *lds_fail = 0;
+    if (tid < 4) lds_rec[tid] = 0;
+    if (__syncthreads_or(__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return;
+
+    // The workgroup's row block through a buffer descriptor: row i, column step s = scalar offset i pitch + 8 KB s, the thread's
+    // column pair = ONE 32-bit byte offset.  Whatever lies outside the block reads as 0 (range check): the rows behind the last
+    // one (never published) and the tail of the block's last row; the last column step of any other row may reach into the
+    // next row -- the product is with p = 0 there (the thread's column is >= n), i.e. exactly 0.
+    const rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(a.A) + (size_t)row0 * a.lda, 0,
+                                                          (int)((long)my_rows * a.lda * 8), 0x00020000);
+    const int pitch_b = (int)(a.lda * 8);
+    const unsigned voff = 16u * (unsigned)tid;
+    auto a_issue = [&](int i, int s) { return as_d2(__builtin_amdgcn_raw_buffer_load_b128(rs_a, voff, i * pitch_b + 16 * T * s, kAuxNt)); };
+    // the exchange buffer: [2 parities][1024 S tagged doubles of 16 bytes]
+    const rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, 2 * a.xslots * 16, 0x00020000);
+
+    // The ring.  It is FILLED by the sweep loop itself (a batch -1 in front of the launch's first iteration: FMAs on zeros, its
+    // row sums dropped), not by loads in front of the loop: the compiler's wait in front of a slot is exact (vmcnt(RB S - 1):
+    // every other slot stays in flight) only when the loads it counts reach the loop's head in ONE order -- with a separate
+    // fill the scheduler issued those loads in an order of its own and the loop began every batch with vmcnt(0) (seen in the ISA).
+    d2 ring[RB][S];
+#pragma unroll
+    for (int j = 0; j < RB; ++j)
+#pragma unroll
+        for (int s = 0; s < S; ++s) ring[j][s] = d2{0.0, 0.0};
+    int b_first = -1;
+
+    // ---- state: r, p for this thread's columns (replicated in every workgroup; exactly 0 in the pad columns n ... 1024 S,
+    // where the gathered Ap is a published 0 as well: no masks inside the loop); x for the workgroup's own rows only
+    const double *st_x = a.in, *st_r = a.in + state_off_r(a.lda), *st_p = a.in + state_off_p(a.lda);
+    const Scalars *st_sc = reinterpret_cast<const Scalars *>(a.in + state_off_sc(a.lda));
+    d2 r[S], p[S];
+    // x of the workgroup's own rows: the thread whose column pair lies in them keeps x and a second copy (rx, px) of its r and p
+    // pair, advanced by the same operations (same bits): the update needs no "is this my column step" test per step then
+    d2 xo = {0.0, 0.0}, rx = {0.0, 0.0}, px = {0.0, 0.0};
+    int sx = -1;
+    bool ox0 = false, ox1 = false;
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+        const int c = 2 * T * s + 2 * tid;
+        const bool ok0 = c < n, ok1 = c + 1 < n;
+        r[s].x = ok0 ? st_r[c] : 0.0;
+        r[s].y = ok1 ? st_r[c + 1] : 0.0;
+        if (a.k0 > 0) {
+            p[s].x = ok0 ? st_p[c] : 0.0;
+            p[s].y = ok1 ? st_p[c + 1] : 0.0;
+        } else {
+            p[s] = r[s];                              // p = r, cg.cc:85
+        }
+        // x: only the workgroup's own rows [row0, row0 + my_rows): fewer than 1024 columns, i.e. at most one s for a thread
+        const bool own0 = c >= row0 && c < row0 + my_rows, own1 = c + 1 >= row0 && c + 1 < row0 + my_rows;
+        if (own0 || own1) {
+            sx = s;
+            ox0 = own0;
+            ox1 = own1;
+            if (own0) xo.x = st_x[c];
+            if (own1) xo.y = st_x[c + 1];
+            rx = r[s];
+            px = p[s];
+        }
+    }
+    const int ap_own = (sx < 0 ? 0 : sx) * T + tid;   // where the gathered Ap of the owned pair is parked
+    double rsold, rs_prev;
+    if (a.k0 > 0) {
+        rsold = st_sc->rs[a.k0 & 1];
+        rs_prev = st_sc->rs[(a.k0 + 1) & 1];
+    } else {
+        double v = 0.0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) v += r[s].x * p[s].x + r[s].y * p[s].y;   // rsold = r.p, cg.cc:91-92
+        rsold = block_sum<W>(v, lds_sum);
+        rs_prev = rsold;
+    }
+
+    // Every load of the state has landed before the loop is entered (a real s_waitcnt, which the compiler's bookkeeping sees): with
+    // p possibly still in flight from a branch in front of the loop, the loop's FIRST use of p was a vmcnt(0) in every batch,
+    // i.e. the ring drained once per batch (seen in the ISA: no vmcnt(RB S - 1) anywhere).
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+
+    // what this thread publishes: the row sum of row row0 + tid (tid < my_rows), or -- dealt over the spare threads of all
+    // workgroups -- a ZERO for one of the pad columns n ... 1024 S - 1, so that every word a gather reads validates itself
+    int pub_col = -1;
+    if (tid < my_rows) {
+        pub_col = row0 + tid;
+    } else {
+        const int i = (tid - my_rows) * (int)gridDim.x + (int)blockIdx.x;
+        if (i < 2 * T * S - n) pub_col = n + i;
+    }
+    const unsigned pub_off = 16u * (unsigned)xpos(pub_col < 0 ? 0 : pub_col);
+
+    const unsigned goff = (unsigned)(16 * (128 * wave + lane));   // the thread's slot inside a 1024-column step of the exchange buffer
+    int k = a.k0, stop = 0;
+    const int k_end = a.k0 + a.iters;
+    unsigned long long epoch = a.epoch0;
+    for (; k < k_end; ++k) {
+        ++epoch;
+        const unsigned tag = p2p_tag(epoch);
+        const int par_b = (int)(epoch & 1) * a.xslots * 16;       // this epoch's half of the exchange buffer
+        double *dot = lds_dot + (k & 1) * 2 * W;
+
+        // diagnostics (CGX_RESIDENT_PROFILE=1): in four iterations of the launch (20, 21, 40, 80) every workgroup notes when it began its sweep, when it
+        // had its row sums, and when it had gathered all of Ap (100-MHz wall clock), and which XCD it runs on
+        const int sj = (k - a.k0 == 20) ? 0 : (k - a.k0 == 21) ? 1 : (k - a.k0 == 40) ? 2 : (k - a.k0 == 80) ? 3 : -1;
+        const bool stamp = a.prof != nullptr && tid == 0 && sj >= 0;
+        long long *pst = a.prof + 8 + 4 * (256 * (sj < 0 ? 0 : sj) + blockIdx.x);
+        if (stamp) pst[0] = wall_clock64();
+
+        // Ap_sub = A_sub p (cblas_dgemv, cg.cc:100-102): batch b = rows b RB ... b RB + RB - 1, the thread's columns ascending;
+        // every slot of the ring is re-issued for the batch after this one as soon as it has been consumed (the fence pins
+        // that order: loads return in order, so the wait in front of slot q leaves the other RB S - 1 in flight)
+        for (int b = b_first; b < nb; ++b) {
+            const int nxt = (b + 1 < nb) ? (b + 1) * RB : 0;      // behind the last batch: the first one of the next iteration
+            double v[RB];
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const d2 av = ring[j][s];
+                    s0 = fma(av.x, p[s].x, s0);
+                    s1 = fma(av.y, p[s].y, s1);
+                    ring[j][s] = a_issue(nxt + j, s);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                v[j] = s0 + s1;
+            }
+            const int myrow = batch_sum<RB>(v, lane);
+            if (b >= 0 && (lane & (64 / RB - 1)) == 0) lds_red[wave * R + b * RB + myrow] = v[0];
+        }
+        b_first = 0;
+        lds_barrier();
+        if (stamp) pst[1] = wall_clock64();   // (behind the barrier: the workgroup's LAST wave has its sums)
+        if (pub_col >= 0 && !(k == a.k0 && (int)blockIdx.x == a.mute_wg)) {   // (mute_wg: the test of the bounded waits)
+            double ap = 0.0;
+            if (tid < my_rows) {
+                const double *q = lds_red + tid;
+                ap = ((q[0] + q[R]) + (q[2 * R] + q[3 * R])) + ((q[4 * R] + q[5 * R]) + (q[6 * R] + q[7 * R]));
+            }
+            const unsigned long long bits = (unsigned long long)__double_as_longlong(ap);
+            const u4 w = {(unsigned)bits, tag, (unsigned)(bits >> 32), tag};
+            __builtin_amdgcn_raw_buffer_store_b128(w, rs_x, pub_off, par_b, kAuxSc1);
+        }
+
+        // gather Ap: one watched word first (column 2 tid), then the thread's columns in chunks of CH steps
+        double pap = 0.0;
+        {
+            const long long t0 = wall_clock64();
+            bool expired = false;
+            int wr = 0;
+            for (;;) {
+                asm volatile("" ::: "memory");
+                const u4 w = __builtin_amdgcn_raw_buffer_load_b128(rs_x, goff, par_b, kAuxSc1);
+                ++wr;
+                if (__all(tag_ok(w, tag))) break;      // the wave goes on together: every branch of the exchange is a scalar one
+                if (wall_clock64() - t0 > a.timeout_ticks) { expired = true; break; }
+            }
+            int gr = 0;
+#pragma unroll
+            for (int c0 = 0; c0 < S; c0 += CH) {
+                u4 w[2 * CH];
+                bool ok;
+                do {
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) {
+                        const int s = c0 + i < S ? c0 + i : S - 1;
+                        w[2 * i] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, goff, par_b + 32 * T * s, kAuxSc1);
+                        w[2 * i + 1] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, goff + 1024, par_b + 32 * T * s, kAuxSc1);
+                    }
+                    ok = true;
+#pragma unroll
+                    for (int i = 0; i < 2 * CH; ++i) ok = ok && tag_ok(w[i], tag);
+                    ok = __all(ok);
+                    if (!ok) {
+                        ++gr;
+                        if (wall_clock64() - t0 > a.timeout_ticks) { expired = true; ok = true; }
+                    }
+                } while (!ok);
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    const int s = c0 + i;
+                    if (s >= S) continue;
+                    d2 g;
+                    g.x = tagged_value(w[2 * i]);
+                    g.y = tagged_value(w[2 * i + 1]);
+                    pap += p[s].x * g.x + p[s].y * g.y;                   // cg.cc:105-106
+                    lds_ap[s * T + tid] = g;
+                }
+            }
+            // what the exchange of this iteration cost, kept only when a poll had to be repeated (or for the launch's first
+            // iteration, where a workgroup that was placed late shows): a.rec, resident_record
+            if (tid == 0 && (wr + gr > 1 || k == a.k0)) {
+                atomicAdd(lds_rec, (unsigned)(wr - 1));
+                atomicAdd(lds_rec + 1, (unsigned)gr);
+                atomicMax(lds_rec + (k == a.k0 ? 2 : 3), (unsigned)(wall_clock64() - t0));
+            }
+            if (stamp) {
+                pst[2] = wall_clock64();
+                pst[3] = __builtin_amdgcn_s_getreg(GETREG_IMMED(4 - 1, 0, 20)) & 0xf;   // XCC_ID[3:0]
+            }
+            if (expired) {
+                atomicExch(a.err, 1);
+                *lds_fail = 1;
+            }
+        }
+
+        pap = wave_sum_swap(pap);
+        if (lane == 0) dot[wave] = pap;
+        lds_barrier();
+        if (*lds_fail) return;         // uniform: written in front of the barrier
+        const double conj = ((dot[0] + dot[1]) + (dot[2] + dot[3])) + ((dot[4] + dot[5]) + (dot[6] + dot[7]));
+        const double alpha = safeguarded_alpha(rsold, conj);             // cg.cc:107
+        double rr = 0.0;
+        {
+            const d2 g = lds_ap[ap_own];
+            xo.x = fma(alpha, px.x, xo.x);                               // cg.cc:110, the workgroup's own rows
+            xo.y = fma(alpha, px.y, xo.y);
+            rx.x = fma(-alpha, g.x, rx.x);
+            rx.y = fma(-alpha, g.y, rx.y);
+        }
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const d2 g = lds_ap[s * T + tid];
+            r[s].x = fma(-alpha, g.x, r[s].x);                           // cg.cc:113
+            r[s].y = fma(-alpha, g.y, r[s].y);
+            rr += r[s].x * r[s].x + r[s].y * r[s].y;                     // cg.cc:116
+        }
+        rr = wave_sum_swap(rr);
+        if (lane == 0) dot[W + wave] = rr;
+        lds_barrier();
+        const double *dr = dot + W;
+        const double rsnew = ((dr[0] + dr[1]) + (dr[2] + dr[3])) + ((dr[4] + dr[5]) + (dr[6] + dr[7]));   // cg.cc:116-117
+        if (sqrt(rsnew) < a.tol) {                                       // cg.cc:120-121: break before the p update
+            rs_prev = rsnew;
+            stop = 1;
+            break;
+        }
+        const double beta = rsnew / rsold;                               // cg.cc:124
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            p[s].x = fma(beta, p[s].x, r[s].x);                          // cg.cc:127-129
+            p[s].y = fma(beta, p[s].y, r[s].y);
+        }
+        px.x = fma(beta, px.x, rx.x);
+        px.y = fma(beta, px.y, rx.y);
+        rs_prev = rsold;
+        rsold = rsnew;                                                   // cg.cc:132
+    }
+
+    // ---- state back to memory: x by the workgroup that owns the rows, r / p / scalars by workgroup 0
+    // (into the OUTPUT set: the state the launch started from stays intact, cgx_kernels.h)
+    if (sx >= 0) {
+        const int c = 2 * T * sx + 2 * tid;
+        if (ox0) a.out[c] = xo.x;
+        if (ox1) a.out[c + 1] = xo.y;
+    }
+    if (blockIdx.x == 0) {
+        double *r_out = a.out + state_off_r(a.lda), *p_out = a.out + state_off_p(a.lda);
+        Scalars *sc_out = reinterpret_cast<Scalars *>(a.out + state_off_sc(a.lda));
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            const int c = 2 * T * s + 2 * tid;
+            if (c < n) { r_out[c] = r[s].x; p_out[c] = p[s].x; }
+            if (c + 1 < n) { r_out[c + 1] = r[s].y; p_out[c + 1] = p[s].y; }
+        }
+        if (tid == 0) {
+            sc_out->rs[k & 1] = rsold;
+            sc_out->rs[(k + 1) & 1] = rs_prev;
+            sc_out->k_final = stop ? k : 0;
+            sc_out->done = stop;
+        }
+    }
+    if (tid == 0 && a.rec) resident_record(a.rec, blockIdx.x == 0, k - a.k0 + stop, lds_rec[0], lds_rec[1], lds_rec[2], lds_rec[3]);
+    // the ring's last loads (the rows of an iteration that never comes) are simply dropped with the wave
+}
+
+template <int S, int RB, int CH>
+hipError_t with_stream_kernel(const ResidentPlan &pl, const ResidentArgs *a, hipStream_t s, int *per_cu)
+{
+    auto kern = k_cg_stream<S, RB, CH>;
+    if (!a) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);
+        if (e != hipSuccess) return e;
+        return hipOccupancyMaxActiveBlocksPerMultiprocessor(per_cu, kern, kStrThreads, pl.lds_bytes);
+    }
+    hipLaunchKernelGGL(kern, dim3(pl.grid), dim3(kStrThreads), pl.lds_bytes, s, *a);
+    return hipGetLastError();
+}
+
+// ring depth: RB rows of S column steps, 12-20 slots of 16 bytes per thread in flight (96-160 KB per CU)
+constexpr int stream_rb(int S) { return S <= 2 ? 8 : S <= 5 ? 4 : S <= 10 ? 2 : 1; }
+constexpr int stream_ch(int S) { return S <= 4 ? S : S <= 9 ? 4 : 2; }
+
+template <int S>
+hipError_t stream_dispatch_s(const ResidentPlan &pl, const ResidentArgs *a, hipStream_t s, int *per_cu)
+{
+    return with_stream_kernel<S, stream_rb(S), stream_ch(S)>(pl, a, s, per_cu);
+}
+
+}  // namespace
+
+hipError_t stream_dispatch(const ResidentPlan &pl, const ResidentArgs *a, hipStream_t s, int *per_cu)
+{
+    switch (pl.S) {
+    case 1: return stream_dispatch_s<1>(pl, a, s, per_cu);
+    case 2: return stream_dispatch_s<2>(pl, a, s, per_cu);
+    case 3: return stream_dispatch_s<3>(pl, a, s, per_cu);
+    case 4: return stream_dispatch_s<4>(pl, a, s, per_cu);
+    case 5: return stream_dispatch_s<5>(pl, a, s, per_cu);
+    case 6: return stream_dispatch_s<6>(pl, a, s, per_cu);
+    case 7: return stream_dispatch_s<7>(pl, a, s, per_cu);
+    case 8: return stream_dispatch_s<8>(pl, a, s, per_cu);
+    case 9: return stream_dispatch_s<9>(pl, a, s, per_cu);
+    case 10: return stream_dispatch_s<10>(pl, a, s, per_cu);
+    case 11: return stream_dispatch_s<11>(pl, a, s, per_cu);
+    case 12: return stream_dispatch_s<12>(pl, a, s, per_cu);
+    case 13: return stream_dispatch_s<13>(pl, a, s, per_cu);
+    case 14: return stream_dispatch_s<14>(pl, a, s, per_cu);
+    case 15: return stream_dispatch_s<15>(pl, a, s, per_cu);
+    case 16: return stream_dispatch_s<16>(pl, a, s, per_cu);
+    }
+    return hipErrorInvalidValue;
+}
+
+bool plan_stream(int n, int cus, size_t lds_per_wg, ResidentPlan *out)
+{
+    ResidentPlan pl{};
+    if (n < 1024 || n > 1024 * 16 || cus < 1) return false;   // (the watched word is column 2 tid < 1024: n >= 1024)
+    const int G = cus < 256 ? cus : 256;
+    pl.stream = 1;
+    pl.S = (n + 1023) / 1024;
+    pl.RB = stream_rb(pl.S);
+    pl.xslots = 1024 * pl.S;
+    pl.R = ((n + G - 1) / G + pl.RB - 1) / pl.RB * pl.RB;     // rows per workgroup, a whole number of batches
+    pl.rows_per_wg = pl.R;
+    pl.grid = (n + pl.R - 1) / pl.R;
+    pl.lds_bytes = ((size_t)kStrWaves * pl.R + 4 * kStrWaves + kStrWaves + 4 + (size_t)2 * pl.S * kStrThreads) * sizeof(double);
+    if (pl.R >= kStrThreads || pl.lds_bytes > lds_per_wg) return false;
+    *out = pl;
+    return true;
+}
+
+}  // namespace cgx

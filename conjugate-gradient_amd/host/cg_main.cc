@@ -407,14 +407,28 @@ int main(int argc, char **argv)
                 const cgx_result &r = solver.last_result();
                 const int it = r.iterations + (r.converged ? 1 : 0);   // loop bodies executed
                 int plan[CGX_GEMV_PLAN_INTS] = {0};
-                (void)cgx_get_gemv_plan(solver.context(), 0, plan);     // variant 4: the loop ran as one resident persistent kernel
+                (void)cgx_get_gemv_plan(solver.context(), 0, plan);     // variant 4 / 5: the loop ran as one persistent kernel
+                long long rec[CGX_RESIDENT_RECORD_INTS] = {0};
+                (void)cgx_get_resident_record(solver.context(), rec);
+                const bool persistent = plan[0] == 4 || plan[0] == 5;
                 std::cerr << "cgsolver stats: n=" << n << " gpus=" << psize << " loop_bodies=" << it
                           << " loop_s=" << r.seconds_loop << " iterations_per_s=" << (r.seconds_loop > 0 ? it / r.seconds_loop : 0.)
                           << " format=" << (banded ? "banded" : "dense")
-                          << " loop=" << (plan[0] == 4 ? "resident-kernel" : "per-launch") << " gemv_ms_avg=" << r.gemv_ms_avg
-                          << " gemv_GBps_per_gpu=" << (r.gemv_ms_avg > 0 ? r.gemv_bytes / (r.gemv_ms_avg * 1e-3) / 1e9 : 0.)
-                          << " hbm_roofline_frac=" << (r.gemv_ms_avg > 0 ? r.gemv_bytes / (r.gemv_ms_avg * 1e-3) / 8.0e12 : 0.)
-                          << std::endl;
+                          << " loop=" << (plan[0] == 4 ? "resident-kernel" : plan[0] == 5 ? "streaming-persistent-kernel" : "per-launch");
+                if (persistent) {
+                    // no K1 launches to time: the whole loop against the algorithmic bytes of its GEMVs, and what its waits cost
+                    // (cgx_get_resident_record; ticks of 10 ns)
+                    std::cerr << " gemv_ms_avg=n/a loop_GBps=" << (r.seconds_loop > 0 ? it * r.gemv_bytes / r.seconds_loop / 1e9 : 0.)
+                              << " loop_hbm_roofline_frac=" << (r.seconds_loop > 0 ? it * r.gemv_bytes / r.seconds_loop / 8.0e12 : 0.)
+                              << " launches=" << rec[3] << " watch_repeats=" << rec[1] << " gather_repeats=" << rec[2]
+                              << " first_wait_us=" << rec[4] / 100.0 << " longest_later_wait_us=" << rec[5] / 100.0
+                              << " first_wait_us_any_wg=" << rec[6] / 100.0 << " longest_later_wait_us_any_wg=" << rec[7] / 100.0;
+                } else {
+                    std::cerr << " gemv_ms_avg=" << r.gemv_ms_avg
+                              << " gemv_GBps_per_gpu=" << (r.gemv_ms_avg > 0 ? r.gemv_bytes / (r.gemv_ms_avg * 1e-3) / 1e9 : 0.)
+                              << " hbm_roofline_frac=" << (r.gemv_ms_avg > 0 ? r.gemv_bytes / (r.gemv_ms_avg * 1e-3) / 8.0e12 : 0.);
+                }
+                std::cerr << " persistent_launches_redone_per_launch=" << rec[8] << std::endl;
             }
         }
     } catch (const std::exception &e) {

@@ -75,14 +75,29 @@ typedef struct cgx_config {
     int  nranks;              /* number of row blocks (the reference's psize)               */
     unsigned char unique_id[CGX_UNIQUE_ID_BYTES]; /* CGX_COMM_RCCL: from cgx_comm_unique_id */
     int  gemv_variant;        /* 0 = library default: the per-launch path (K1 + K3 per iteration) with the K1 shape chosen from the
-                                 block size -- or, for a dense matrix of n <= 4096 on one GPU (CGX_COMM_SELF), the resident
-                                 solver: the whole loop cg.cc:95-137 as ONE persistent kernel, every row group of A held in a
-                                 CU's LDS (n <= 2048) or in its LDS and registers with a streamed rest (n <= 4096)
-                                 (csrc/cgx_resident.hip; 3-9 us per iteration instead of 7-26).
-                                 40000 = ask for the LDS-resident solver (CGX_ERR_UNSUPPORTED where it cannot be had);
-                                 -1 = the per-launch path with its default shape, also where the resident solver would fit
-                                 (as does CGX_RESIDENT=0 in the environment); v*10000 + R*100 + U*10 + d = an explicit
-                                 per-launch K1 shape, see DESIGN.md "K1 variants"              */
+                                 block size -- or, for a dense matrix of n <= 16384 on one GPU (CGX_COMM_SELF), a PERSISTENT kernel:
+                                 the whole loop cg.cc:95-137 as ONE launch whose workgroups exchange Ap among themselves.
+                                 n <= 4096: every row group of A stays on the chip, in a CU's LDS (n <= 2048) or in its LDS and
+                                 registers with a streamed rest (csrc/cgx_resident.hip; 3-9 us per iteration instead of 7-26);
+                                 4096 < n <= 16384: every row is streamed, the vectors stay in registers (csrc/cgx_stream.hip;
+                                 DESIGN.md section 4c).  What the default choice rests on, and what happens when it fails:
+                                 all workgroups of such a kernel must be resident at once (checked against the runtime's
+                                 occupancy when the problem is set; another tenant of the GPU can still break it), and the
+                                 exchange rests on an aligned 8-byte half of a 16-byte write-through store being seen untorn
+                                 by another CU -- observed on gfx950 / ROCm 7.2, not an architectural guarantee (the same
+                                 caveat as p2p_tagged below).  Every wait inside the kernel is bounded (p2p_timeout_ms); a
+                                 launch whose wait expires has written nothing of the solver's state, and under the DEFAULT
+                                 choice the library redoes it on the per-launch path and stays there for the rest of the
+                                 problem: the call returns CGX_OK, cgx_get_gemv_plan then reports the per-launch shape,
+                                 cgx_get_resident_record counts the event and cgx_last_error holds a note.
+                                 40000 = ask for the persistent kernel: CGX_ERR_UNSUPPORTED where it cannot be had, and an
+                                 expired wait is CGX_ERR_HIP (no fallback; the context stays usable for the next problem);
+                                 50000 = the same, but the STREAMING persistent kernel whatever the size (1024 <= n <= 16384);
+                                 -1 = the per-launch path with its default shape, also where a persistent kernel would fit
+                                 (as does CGX_RESIDENT=0 in the environment; CGX_STREAM_MAX=n moves the upper end of the
+                                 default, 4096 = never stream); v*10000 + R*100 + U*10 + d = an explicit per-launch K1 shape,
+                                 see DESIGN.md "K1 variants".  profile_gemv, profile_update and check_every do not apply to
+                                 a persistent kernel (there are no K1 launches to time and no polls: gemv_ms_* stay 0). */
     int  lda_pad;             /* extra doubles added to the row pitch (-1 = library default)*/
     int  check_every;         /* iterations between host polls of the device `done` flag (0 = default) */
     int  profile_gemv;        /* n > 0 = bracket every n-th K1 launch with HIP events (at most 2048 per cgx_solve_steps call);
@@ -153,13 +168,25 @@ cgx_status  cgx_get_comm_info(cgx_ctx *ctx, int *comm_mode, int *ranks_wired, in
 
 /* The K1 (GEMV, cg.cc:100-102) launch shape the library planned for local shard `local_shard` of the current problem,
  * for the benchmark record (which kernel ran): out = {variant (1 column-split, 2 LDS-staged p tiles, 3 banded, 4 = the loop
- * runs in the resident persistent kernel), R rows per workgroup (variant 2: per wave), U steps in flight (variant 4:
- * column steps of 512), waves per workgroup, light (1 = the one-round form; variant 4: rows of a workgroup held in
- * registers, 0 up to n = 2048), split (column pieces per row group, tied to the
- * XCDs), grid (workgroups of one fused launch; variant 4: of the persistent kernel, all resident at once), ncols (columns
- * swept)}. */
+ * runs in the resident persistent kernel, 5 = in the streaming persistent kernel), R rows per workgroup (variant 2: per
+ * wave), U steps in flight (variant 4 / 5: column steps of 512 / 1024), waves per workgroup, light (1 = the one-round form;
+ * variant 4: rows of a workgroup held in registers, 0 up to n = 2048; variant 5: rows per batch of the ring), split (column
+ * pieces per row group, tied to the XCDs), grid (workgroups of one fused launch; variant 4 / 5: of the persistent kernel, all
+ * resident at once), ncols (columns swept)}.  After a persistent launch has been redone on the per-launch path (gemv_variant
+ * above) this reports the per-launch shape. */
 #define CGX_GEMV_PLAN_INTS 8
 cgx_status  cgx_get_gemv_plan(const cgx_ctx *ctx, int local_shard, int out[CGX_GEMV_PLAN_INTS]);
+
+/* What the waits inside the persistent launches of the current (or most recent) solve cost, so that a slow solve can say why:
+ * out = {[0] iterations run, [1] polls of the watched word that had to be repeated, [2] gather rounds that had to be repeated,
+ * [3] launches -- all four as workgroup 0 saw them --, [4] workgroup 0: 100-MHz wall-clock ticks from its publish of a
+ * launch's FIRST iteration until it had all of Ap (a workgroup that was placed late shows here; largest over the launches),
+ * [5] workgroup 0: the longest such span of a LATER iteration in which a poll had to be repeated (the exchange itself; 0 =
+ * never), [6] / [7] the same two, largest over ALL workgroups, [8] persistent launches of this context, over its whole life,
+ * whose waits expired and that were redone on the per-launch path, [9] 1 = the current problem is on a persistent kernel}.
+ * Costs no synchronisation: the record comes back with {done, k_final} behind every launch. */
+#define CGX_RESIDENT_RECORD_INTS 10
+cgx_status  cgx_get_resident_record(const cgx_ctx *ctx, long long out[CGX_RESIDENT_RECORD_INTS]);
 
 /* ---- CGX_COMM_P2P wire-up (replaces MPI_Init's job for the direct-xGMI transport) --------- */
 /* export: this rank's mailbox as an IPC handle.  import: all ranks' handles, rank order (nranks * 64 bytes),

@@ -23,5 +23,5 @@ for r in rows:
     if len(sys.argv) > 1 and sys.argv[1] not in name:
         continue
     print("%-60s vgpr=%-4s sgpr=%-4s spill=%s/%s lds=%-6s occ=%s" % (
-        name[:60], r.get("VGPRs"), r.get("TotalSGPRs", r.get("SGPRs")), r.get("VGPR Spill", r.get("VGPRs Spill")),
+        name[-44:], r.get("VGPRs"), r.get("TotalSGPRs", r.get("SGPRs")), r.get("VGPR Spill", r.get("VGPRs Spill")),
         r.get("SGPRs Spill", r.get("SGPR Spill")), r.get("LDS Size [bytes/block]"), r.get("Occupancy [waves/SIMD]")))
