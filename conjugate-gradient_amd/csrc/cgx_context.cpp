@@ -21,8 +21,10 @@ using namespace cgxi;
 
 namespace cgxi {
 
-// Largest n the DEFAULT choice hands to the streaming persistent kernel (measured against the per-launch path: DESIGN.md section 4c)
-constexpr int kStreamDefaultMax = 16384;
+// Largest n the DEFAULT choice hands to the streaming persistent kernel: measured against the per-launch path it wins up to
+// N = 8192 (31.7 / 44.7 / 78.7 us per iteration at N = 5120 / 6144 / 8192 against 35.7 / 47.8 / 79.8) and loses above (122 against
+// 119 at N = 10000): with equal static shares a sweep ends with its slowest workgroup
+constexpr int kStreamDefaultMax = 8192;
 
 thread_local std::string g_create_error;
 

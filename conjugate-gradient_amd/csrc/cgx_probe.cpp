@@ -206,7 +206,8 @@ cgx_status cgx_probe_set_p2p_epoch(cgx_ctx *ctx, int chan, unsigned long long va
 cgx_status cgx_probe_resident_test(cgx_ctx *ctx, unsigned long long epoch, int mute_workgroup)
 {
     if (!ctx) return CGX_ERR_BAD_ARG;
-    if (ctx->in_solve) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_probe_resident_test inside begin/end");
+    // (the epoch only between solves; muting a workgroup of the next launch also between two cgx_solve_steps calls)
+    if (ctx->in_solve && epoch > 0) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_probe_resident_test: the epoch cannot be moved inside begin/end");
     if (epoch > 0) {
         if (epoch < ctx->res_epoch) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_probe_resident_test: the epoch can only move forward");
         ctx->res_epoch = epoch;

@@ -214,7 +214,9 @@ def test_selection(gpu_pkg, monkeypatch):
         assert s.gemv_plan()["variant"] == 4
     with lap(gpu_pkg, 4096, 0) as s:
         assert s.gemv_plan()["variant"] == 4
-    with lap(gpu_pkg, 4097, 0) as s:
+    with lap(gpu_pkg, 4097, 0) as s:               # above 4096 the matrix no longer fits the chip: the STREAMING persistent kernel
+        assert s.gemv_plan()["variant"] == 5       # (csrc/cgx_stream.hip, tests/test_gpu_stream.py), by default up to n = 8192
+    with lap(gpu_pkg, 8193, 0) as s:
         assert s.gemv_plan()["variant"] == 1
     with lap(gpu_pkg, 1024, 10421) as s:
         assert s.gemv_plan()["variant"] == 1
@@ -226,8 +228,10 @@ def test_selection(gpu_pkg, monkeypatch):
     with lap(gpu_pkg, 1024, RESIDENT) as s:       # the explicit request is not overridden by the environment
         assert s.gemv_plan()["variant"] == 4
     monkeypatch.delenv("CGX_RESIDENT")
+    with lap(gpu_pkg, 4097, RESIDENT) as s:        # asked for: a persistent kernel up to n = 16384
+        assert s.gemv_plan()["variant"] == 5
     with pytest.raises(gpu_pkg.CgxError) as e:
-        lap(gpu_pkg, 4097, RESIDENT)
+        lap(gpu_pkg, 16385, RESIDENT)
     assert "does not fit" in str(e.value)
     with gpu_pkg.CGSolver(comm_mode=gpu_pkg.COMM_LOOPBACK, nranks=2, gemv_variant=0) as s:
         s.generate_lap2d_matrix(1024)
@@ -309,7 +313,8 @@ def test_epoch_wrap_of_the_tag(gpu_pkg, n):
 @pytest.mark.parametrize("n", [1024, 4096])
 def test_a_wait_that_expires_is_reported(gpu_pkg, n):
     """Every wait inside the kernel is bounded: a workgroup that never publishes (test hook) makes the waits for it expire after
-    p2p_timeout_ms; the call returns an error instead of hanging, and a new context solves as before."""
+    p2p_timeout_ms.  Asked for explicitly (gemv_variant 40000) the call returns an error instead of hanging -- and the context
+    is NOT dead: the next solve starts with the error word down and gives the bits of a fresh context."""
     import time
     x_good = None
     for mute in (0, 37, 255):
@@ -325,13 +330,159 @@ def test_a_wait_that_expires_is_reported(gpu_pkg, n):
             with pytest.raises(gpu_pkg.CgxError) as e:
                 s.solve(np.zeros(n))
             assert "expired" in str(e.value) and time.perf_counter() - t0 < 5.0
-            # the error word is sticky for this context (like the P2P transport's): a new context is the way on
-            with pytest.raises(gpu_pkg.CgxError):
-                s.solve(np.zeros(n))
+            assert s.resident_record()["fallbacks"] == 0
+            x = np.zeros(n)
+            s.solve(x)                                   # same context, same problem
+            assert np.array_equal(x, x_good)
+            s.generate_lap2d_matrix(n)                   # same context, the problem set again
+            s.set_max_iter(50)
+            s.tolerance(0.0)
+            s.init_source_term(1.0 / n)
+            x = np.zeros(n)
+            s.solve(x)
+            assert np.array_equal(x, x_good)
     with lap(gpu_pkg, n, RESIDENT, 50, 0.0) as s:
         x = np.zeros(n)
         s.solve(x)
     assert np.array_equal(x, x_good)
+
+
+@pytest.mark.parametrize("n", [1024, 2048, 4096])
+def test_the_default_choice_falls_back_to_the_per_launch_path(gpu_pkg, oracle, monkeypatch, n):
+    """The same expired wait under the library's DEFAULT choice (gemv_variant 0): the launch has written nothing of the solver's
+    state, the library redoes it on the per-launch path and the call returns CGX_OK with the oracle's result; the plan then
+    reports the per-launch shape, the record counts the event, and the context goes on working -- the same problem on the
+    per-launch path, the next problem on the persistent kernel again."""
+    monkeypatch.delenv("CGX_RESIDENT", raising=False)
+    import time
+    iters = 50
+    xo, ro = oracle.solve_lap2d(n, iters, 0.0, 1)
+    with gpu_pkg.CGSolver(gemv_variant=0, p2p_timeout_ms=200) as s:
+        s.generate_lap2d_matrix(n)
+        s.set_max_iter(iters)
+        s.tolerance(0.0)
+        s.init_source_term(1.0 / n)
+        assert s.gemv_plan()["variant"] == 4
+        s._resident_test(mute_workgroup=37 % s.gemv_plan()["grid"])
+        t0 = time.perf_counter()
+        x = np.zeros(n)
+        r = s.solve(x)
+        assert time.perf_counter() - t0 < 5.0
+        assert r["iterations"] == iters and np.linalg.norm(x - xo) <= 1e-12 * np.linalg.norm(xo)
+        assert rel(r["residual_prev"], ro["residual_prev"]) <= 1e-10
+        rec = s.resident_record()
+        assert s.gemv_plan()["variant"] == 1 and rec["fallbacks"] == 1 and rec["persistent"] == 0
+        x2 = np.zeros(n)
+        s.solve(x2)                                      # the same problem again: stays on the per-launch path
+        assert np.array_equal(x2, x) and s.resident_record()["fallbacks"] == 1
+        s.generate_lap2d_matrix(n)                       # the next problem: the persistent kernel gets its chance again
+        s.set_max_iter(iters)
+        s.tolerance(0.0)
+        s.init_source_term(1.0 / n)
+        assert s.gemv_plan()["variant"] == 4
+        x3 = np.zeros(n)
+        s.solve(x3)
+        assert np.linalg.norm(x3 - xo) <= 1e-12 * np.linalg.norm(xo) and s.resident_record()["persistent"] == 1
+
+
+@pytest.mark.parametrize("k0", [1, 20, 21])
+def test_fallback_in_the_middle_of_a_solve(gpu_pkg, oracle, monkeypatch, k0):
+    """The wait expires in a LATER launch of a solve (the loop cut into pieces by the caller): the persistent kernels leave p
+    already formed between launches, where the per-launch K1 forms it itself -- the iteration in between runs as the plain K1
+    on the formed p followed by K3, and the solve goes on to the oracle's result."""
+    monkeypatch.delenv("CGX_RESIDENT", raising=False)
+    n, iters = 2048, 60
+    xo, ro = oracle.solve_lap2d(n, iters, 0.0, 1)
+    with gpu_pkg.CGSolver(gemv_variant=0, p2p_timeout_ms=200) as s:
+        s.generate_lap2d_matrix(n)
+        s.set_max_iter(iters)
+        s.tolerance(0.0)
+        s.init_source_term(1.0 / n)
+        s.solve_begin(np.zeros(n))
+        s.solve_steps(k0)
+        assert s.gemv_plan()["variant"] == 4
+        s._resident_test(mute_workgroup=5)
+        s.solve_steps(7)                                  # falls back inside this call
+        assert s.gemv_plan()["variant"] == 1
+        s.solve_steps(iters)
+        x = np.zeros(n)
+        r = s.solve_end(x)
+        assert s.resident_record()["fallbacks"] == 1
+    assert r["iterations"] == iters
+    assert np.linalg.norm(x - xo) <= 1e-12 * np.linalg.norm(xo) and rel(r["residual_prev"], ro["residual_prev"]) <= 1e-10
+
+
+def test_the_record_of_the_waits(gpu_pkg):
+    """cgx_get_resident_record: what the waits of the persistent launches cost comes back with {done, k_final} (no extra
+    synchronisation) and is what `cgsolver --stats` prints."""
+    with lap(gpu_pkg, 2048, RESIDENT, 300, 0.0) as s:
+        s.solve(np.zeros(2048))
+        rec = s.resident_record()
+    assert rec["iterations"] == 300 and rec["launches"] == 1 and rec["persistent"] == 1 and rec["fallbacks"] == 0
+    assert 0 < rec["wg0_first_wait_ticks"] <= rec["max_first_wait_ticks"] < 100000      # ticks of 10 ns: below 1 ms
+    assert rec["wg0_longest_wait_ticks"] <= rec["max_longest_wait_ticks"] < 100000
+
+
+_TENANT = r"""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import __graft_entry__ as g
+pkg = g.load_package()
+n, seconds = int(sys.argv[2]), float(sys.argv[3])
+t0 = time.time()
+done = errors = 0
+with pkg.CGSolver(gemv_variant=40000, p2p_timeout_ms=500) as s:
+    s.generate_lap2d_matrix(n); s.set_max_iter(20000); s.tolerance(0.0); s.init_source_term(1.0 / n)
+    print("READY", flush=True)
+    while time.time() - t0 < seconds:
+        try:
+            s.solve(np.zeros(n)); done += 1
+        except pkg.CgxError:
+            errors += 1
+print("TENANT", done, errors)
+"""
+
+
+def test_another_tenant_of_the_gpu(gpu_pkg, oracle, monkeypatch):
+    """A second process keeps LDS-heavy persistent grids on the GPU (the resident kernel itself at n = 2048, one workgroup per CU,
+    20 000 iterations per launch, WITHOUT the advisory lock: CGX_RESIDENT_NOLOCK) while this process solves n = 2048 under the
+    default choice with a short bound on the waits.  Every solve here ends with CGX_OK and the oracle's result within the bound,
+    by either path (the record says how many went through the fallback)."""
+    import time
+    monkeypatch.delenv("CGX_RESIDENT", raising=False)
+    monkeypatch.setenv("CGX_RESIDENT_NOLOCK", "1")
+    n, iters = 2048, 100
+    xo, _ = oracle.solve_lap2d(n, iters, 0.0, 1)
+    env = dict(os.environ)
+    env.pop("CGX_RESIDENT", None)
+    tenant = subprocess.Popen([sys.executable, "-c", _TENANT, ROOT, str(n), "12"], stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                              text=True, env=env)
+    try:
+        assert tenant.stdout.readline().startswith("READY")
+        fell, solves, worst = 0, 0, 0.0
+        t_end = time.time() + 8.0
+        while time.time() < t_end:
+            with gpu_pkg.CGSolver(gemv_variant=0, p2p_timeout_ms=300) as s:
+                s.generate_lap2d_matrix(n)
+                s.set_max_iter(iters)
+                s.tolerance(0.0)
+                s.init_source_term(1.0 / n)
+                for _ in range(5):
+                    t0 = time.perf_counter()
+                    x = np.zeros(n)
+                    r = s.solve(x)
+                    worst = max(worst, time.perf_counter() - t0)
+                    assert r["iterations"] == iters and np.linalg.norm(x - xo) <= 1e-12 * np.linalg.norm(xo)
+                    solves += 1
+                fell += s.resident_record()["fallbacks"]
+        so, se = tenant.communicate(timeout=120)
+    finally:
+        if tenant.poll() is None:
+            tenant.kill()
+    assert tenant.returncode == 0, so + se
+    assert solves >= 5 and worst < 5.0, (solves, worst)
+    print("solves %d, of which through the fallback %d, slowest %.3f s; %s" % (solves, fell, worst, so.strip().splitlines()[-1]))
 
 
 _WORKER = r"""
