@@ -210,15 +210,14 @@ static cgx_status setup_resident(cgx_ctx *ctx, int variant)
         ctx->res_xbuf_bytes = bytes;
     }
     if (!ctx->d_res_err) HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_res_err), sizeof(int)));
-    if (!ctx->d_res_rec) {
-        HIP_TRY(ctx, hipMalloc(reinterpret_cast<void **>(&ctx->d_res_rec), 8 * sizeof(long long)));
-        HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_res_rec), 8 * sizeof(long long), hipHostMallocDefault));
+    if (!ctx->h_res_tail) {
+        HIP_TRY(ctx, hipHostMalloc(reinterpret_cast<void **>(&ctx->h_res_tail), sizeof(cgx::ResidentTail), hipHostMallocDefault));
+        memset(ctx->h_res_tail, 0, sizeof(cgx::ResidentTail));
     }
     // every problem starts with the error word down (an earlier problem's expired wait must not poison this one: ADVICE r4) and
     // with an exchange buffer of zeros only (no tag is 0): what a reader finds in a position is then a zero or a tagged word of
     // an earlier epoch of THIS geometry, never something another problem size left there
     HIP_TRY(ctx, hipMemsetAsync(ctx->d_res_err, 0, sizeof(int), ctx->stream));
-    HIP_TRY(ctx, hipMemsetAsync(ctx->d_res_rec, 0, 8 * sizeof(long long), ctx->stream));
     HIP_TRY(ctx, hipMemsetAsync(ctx->res_xbuf, 0, ctx->res_xbuf_bytes, ctx->stream));
     if (ctx->res_lock_fd < 0 && !getenv("CGX_RESIDENT_NOLOCK"))   // (the variable: diagnostics, to show what the lock is for)
         ctx->res_lock_fd = open_device_lock(ctx->device);
@@ -259,7 +258,7 @@ cgx_status setup_problem(cgx_ctx *ctx, int n)
     free_problem(ctx);
     ctx->m = ctx->n = n;
     if (n <= (8 << 20) &&
-        hipHostMalloc(reinterpret_cast<void **>(&ctx->h_stage), (size_t)n * sizeof(double), hipHostMallocDefault) != hipSuccess)
+        hipHostMalloc(reinterpret_cast<void **>(&ctx->h_stage), (size_t)(n + 16) * sizeof(double), hipHostMallocDefault) != hipSuccess)
         ctx->h_stage = nullptr;   // not fatal: the copies fall back to the caller's pageable buffer
     ctx->max_iter = n;   // m_maxIter = size, code/MPI/cg.cc:172
     ctx->lda = default_lda(ctx, n);
@@ -819,8 +818,7 @@ cgx_status cgx_destroy(cgx_ctx *ctx)
     }
     (void)hipFree(ctx->res_xbuf);
     (void)hipFree(ctx->d_res_err);
-    (void)hipFree(ctx->d_res_rec);
-    if (ctx->h_res_rec) (void)hipHostFree(ctx->h_res_rec);
+    if (ctx->h_res_tail) (void)hipHostFree(ctx->h_res_tail);
     if (ctx->res_lock_fd >= 0) close(ctx->res_lock_fd);
     for (auto e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (auto e : ctx->upd_pool) (void)hipEventDestroy(e);

@@ -105,9 +105,10 @@ struct cgx_ctx {
     bool res_lock_gave_up = false;           // a wait for that lock ran into its bound once: later launches do not wait again
     int res_mute_wg = -1;                    // test only (cgx_probe_resident_test): workgroup that skips its first publish, next launch
     bool res_forced = false;                 // gemv_variant 40000: a launch whose waits expire is an error, not a fallback
-    long long *d_res_rec = nullptr;          // 8 x 64 bits: what the waits of the launches cost (cgx_tagged.h, resident_record)
-    long long *h_res_rec = nullptr;          // pinned: its copy, read behind every launch together with {done, k_final, error word}
-    long long res_rec[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the most recent copy (cgx_get_resident_record)
+    cgx::ResidentTail *h_res_tail = nullptr; // pinned: what a persistent launch reports (written by the kernel itself, cgx_kernels.h)
+    unsigned res_stamp = 0;                  // the number of the most recent persistent launch (never 0 once one has run)
+    long long res_rec[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the waits of the current solve's launches, summed up (cgx_get_resident_record)
+    bool lean = false;                       // the solve under way began with the one-kernel set-up (zero initial guess, persistent kernel)
     long long res_fallbacks = 0;             // persistent launches of this context whose waits expired and that were redone on the per-launch path
 
     // loopback pointer tables (device)
@@ -120,7 +121,7 @@ struct cgx_ctx {
     bool done = false;
     int k_final = 0;
     int *h_flags = nullptr;   // pinned: 2 polling slots + 1 for read_flags_sync, each {done, k_final}
-    double *h_stage = nullptr;   // pinned, n doubles: x0 in / x out go through it, so that solve() never waits for the
+    double *h_stage = nullptr;   // pinned, n + 16 doubles: x0 in / x out go through it, so that solve() never waits for the
                                  // runtime's first-use set-up of pageable copies (8 ms inside the reference's timing
                                  // window, measured); nullptr above 8 Mi rows (then the copies are direct)
     hipEvent_t flag_ev[2] = {nullptr, nullptr};

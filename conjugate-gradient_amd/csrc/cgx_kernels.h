@@ -266,6 +266,21 @@ __host__ __device__ inline long state_off_r(long lda) { return lda; }
 __host__ __device__ inline long state_off_p(long lda) { return 2 * lda + kStateTail; }
 __host__ __device__ inline long state_off_sc(long lda) { return 3 * lda + kStateTail; }
 __host__ __device__ inline long state_doubles(long lda) { return 3 * lda + kStateTail + 16; }   // Scalars: 96 bytes
+// What a persistent launch reports to the host, written by the kernel straight into pinned host memory (so that a solve needs no
+// copy command for it): workgroup 0 writes the head and, LAST, the launch's stamp -- it does so on every path out of the kernel,
+// also when a wait expired or the error word was already up when it started, and since a kernel is over only when all of its
+// workgroups are, the host finds the stamp of THIS launch behind the stream's synchronisation whatever happened.  Every
+// workgroup writes its own line of `waits` (all of them fresh after any launch that has ended).
+struct ResidentTail {
+    int done, k_final;     // the break of cg.cc:120-121 was taken, in iteration k_final
+    int err;               // a bounded wait expired (or the error word was up at the start)
+    unsigned stamp;        // ResidentArgs::stamp of the launch that wrote this
+    // workgroup 0: iterations run | polls of the watched word that had to be repeated | gather rounds that had to be repeated
+    long long iterations, watch_repeats, gather_repeats;
+    // per workgroup, 100-MHz ticks: from its publish of the launch's FIRST iteration until it had gathered all of Ap (a workgroup
+    // that was placed late shows here) | the longest such span of a LATER iteration in which a poll had to be repeated (0: none)
+    unsigned waits[256][2];
+};
 struct ResidentArgs {
     const double *A;   // n x lda, row-major, pad columns zero
     long lda;
@@ -282,7 +297,8 @@ struct ResidentArgs {
     long long timeout_ticks;    // bound of every wait, 100 MHz wall-clock ticks
     int *err;          // device word raised when a wait expired
     int mute_wg;       // test only (cgx_probe_resident_test): this workgroup leaves out the publish of the launch's first iteration; -1 = none
-    long long *rec;    // 8 x 64 bits or nullptr: what the waits of the launch cost (resident_record, cgx_tagged.h)
+    ResidentTail *tail;   // PINNED HOST memory: what the launch reports back (written by the kernel itself: no copy command)
+    unsigned stamp;    // the launch's number (never 0): workgroup 0's last word into the tail
     long long *prof;   // diagnostics (CGX_RESIDENT_PROFILE=1), else nullptr: workgroup 0 adds up shader-clock cycles per phase
                        // [0] GEMV + row sums + publish, [1] wait for the watched word, [2] gather, [3] p.Ap, [4] update + r.r,
                        // [5] watch rounds, [6] gather rounds, [7] iterations
@@ -298,6 +314,17 @@ hipError_t stream_dispatch(const ResidentPlan &pl, const ResidentArgs *a, hipStr
 // keeps resident per CU (the caller checks grid <= that x CUs: the workgroups wait for each other).
 hipError_t prepare_cg_resident(const ResidentPlan &pl, int *workgroups_per_cu);
 hipError_t launch_cg_resident(const ResidentPlan &pl, const ResidentArgs &a, hipStream_t s);
+
+// ---- a persistent solve from a ZERO initial guess in four launches (n <= 16384, one GPU; cgx_solve.cpp) --------------------------
+// Everything cgx_solve_begin does for x0 = 0 in ONE kernel: x = 0, r = b (b - A 0, cg.cc:79-82: A 0 is exactly 0), one r.r partial
+// per 256 rows behind r (what the per-launch K1 of iteration 0 folds, should the persistent launch have to be redone), both p
+// buffers, the exchanged segments and the scalar block zeroed, the error word down.
+hipError_t launch_solve_begin_zero(int n, long lda, const double *b_full, double *x, SegView rv, double *p0, double *p1, double *apg,
+                                   long apg_count, Scalars *sc, int *err, hipStream_t s);
+// Everything cgx_solve_end does behind the verification GEMV in ONE kernel (one workgroup of 1024 threads, fixed order):
+// out[0 .. n) = x, out[n + 0 .. 2] = sum (Ax - b)^2, sum b^2, sum x^2 (cg.cc:144-151), out[n + 3 .. 4] = sc->rs[0 .. 1]; out is
+// pinned host memory.
+hipError_t launch_solve_end(int n, const double *Ax, const double *b, const double *x, const Scalars *sc, double *out, hipStream_t s);
 
 // Loopback "collective": copy local[kSlots] of every shard into gathered[] of every shard (<= 16 shards).
 hipError_t launch_loopback_gather(double *const *gathered_ptrs, const Scalars *const *scalar_ptrs, int nshards,

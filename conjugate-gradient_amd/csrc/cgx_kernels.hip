@@ -706,6 +706,69 @@ __global__ __launch_bounds__(256) void k_init_residual(int n, const double *__re
 
 // dst[0..count) = src[0..count); either side may be pinned host memory (x0 in / x out of a solve: a kernel instead of
 // a copy-engine transfer, whose first use in a process costs ~8 ms -- inside the reference's timing window).
+// cgx_solve_begin for a ZERO initial guess in one kernel (launch_solve_begin_zero, cgx_kernels.h): x = 0, r = b, the r.r partials
+// behind r in k_init_residual's grouping (one per workgroup), p buffers / exchanged segments / scalar block zeroed, error word down.
+__global__ __launch_bounds__(256) void k_solve_begin_zero(int n, long lda, const double *__restrict__ b_full, double *__restrict__ x,
+                                                           SegView rv, double *__restrict__ p0, double *__restrict__ p1,
+                                                           double *__restrict__ apg, long apg_count, Scalars *sc, int *err)
+{
+    __shared__ double lds[4];
+    double *r = rv.base;
+    double rr = 0.0;
+    const long top = lda > apg_count ? lda : apg_count;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < top; i += (long)gridDim.x * 256) {
+        if (i < lda) {
+            const double bi = i < n ? b_full[i] : 0.0;          // r = b - A 0 = b, cg.cc:79-82
+            x[i] = 0.0;
+            p0[i] = 0.0;
+            p1[i] = 0.0;
+            r[i] = bi;
+            rr += bi * bi;                                      // rsold = r.p with p == r, cg.cc:85,91
+        }
+        if (i < apg_count) apg[i] = 0.0;
+    }
+    rr = block_sum<4>(rr, lds);
+    if (threadIdx.x == 0) r[rv.Sr + blockIdx.x] = rr;
+    if (blockIdx.x == 0) {
+        if (threadIdx.x < sizeof(Scalars) / sizeof(double)) reinterpret_cast<double *>(sc)[threadIdx.x] = 0.0;
+        if (threadIdx.x == 0 && err) *err = 0;
+    }
+}
+
+// cgx_solve_end behind the verification GEMV in one kernel (launch_solve_end): one workgroup, fixed order of summation.
+__global__ __launch_bounds__(1024) void k_solve_end(int n, const double *__restrict__ Ax, const double *__restrict__ b,
+                                                     const double *__restrict__ x, const Scalars *sc, double *__restrict__ out)
+{
+    __shared__ double lds[3][16];
+    double e = 0.0, bb = 0.0, xx = 0.0;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const double xi = x[i], bi = b[i], d = Ax[i] - bi;      // cg.cc:146-151
+        out[i] = xi;
+        e += d * d;
+        bb += bi * bi;
+        xx += xi * xi;
+    }
+    e = wave_sum(e);
+    bb = wave_sum(bb);
+    xx = wave_sum(xx);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+        lds[0][w] = e;
+        lds[1][w] = bb;
+        lds[2][w] = xx;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        double s = lds[threadIdx.x][0];
+        for (int i = 1; i < 16; ++i) s += lds[threadIdx.x][i];
+        out[n + threadIdx.x] = s;
+    }
+    if (threadIdx.x == 3) {
+        out[n + 3] = sc->rs[0];
+        out[n + 4] = sc->rs[1];
+    }
+}
+
 __global__ __launch_bounds__(256) void k_copy_doubles(double *__restrict__ dst, const double *__restrict__ src, long count)
 {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < count; i += (long)gridDim.x * 256) dst[i] = src[i];
@@ -2026,6 +2089,19 @@ hipError_t launch_reduce_partials(const double *partials, int n, double *out, hi
 hipError_t launch_reduce_partials3(const double *partials, int n, double *out3, hipStream_t s)
 {
     hipLaunchKernelGGL((k_reduce_partials<3>), dim3(1), dim3(256), 0, s, partials, n, out3);
+    return hipGetLastError();
+}
+
+hipError_t launch_solve_begin_zero(int n, long lda, const double *b_full, double *x, SegView rv, double *p0, double *p1, double *apg,
+                                   long apg_count, Scalars *sc, int *err, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_solve_begin_zero, dim3(update_xr_grid(n)), dim3(256), 0, s, n, lda, b_full, x, rv, p0, p1, apg, apg_count, sc, err);
+    return hipGetLastError();
+}
+
+hipError_t launch_solve_end(int n, const double *Ax, const double *b, const double *x, const Scalars *sc, double *out, hipStream_t s)
+{
+    hipLaunchKernelGGL(k_solve_end, dim3(1), dim3(1024), 0, s, n, Ax, b, x, sc, out);
     return hipGetLastError();
 }
 

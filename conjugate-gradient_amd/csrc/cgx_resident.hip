@@ -78,12 +78,17 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
     constexpr int kScratch = 4 * R + 8;
     double *lds_red = lds_all + (size_t)RL * pitch;   // two sets of per-iteration scratch
     double *lds_sum = lds_red + 2 * kScratch;         // 4 doubles for block_sum (set-up only)
-    double *lds_fail = lds_sum + 4;                   // one word: a wait of this workgroup expired
+    // one word: a wait of this workgroup expired.  Plain LDS accesses, ordered by the barriers (a `volatile` access through a cast
+    // pointer is a FLAT instruction: its wait is vmcnt(0) and lgkmcnt(0) together)
+    int *lds_fail = reinterpret_cast<int *>(lds_sum + 4);
     const int row0 = blockIdx.x * R;
     const int my_rows = min(R, n - row0);             // >= 1 by construction of the grid
 
-    if (tid == 0) *reinterpret_cast<volatile int *>(lds_fail) = 0;
-    if (__syncthreads_or(__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return;
+    if (tid == 0) *lds_fail = 0;
+    if (__syncthreads_or(__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        if (tid == 0) tail_report(a, 1, 0, a.k0, nullptr);
+        return;
+    }
 
     // a row of the block as this thread sees it: its 2 S columns; rows behind the last one are read as row n-1 (never published),
     // columns behind the pitch as zero (columns n .. lda are zero in the block already)
@@ -274,6 +279,13 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
             const long long t0 = wall_clock64();
             bool expired = false;
             if (prof) tp[1] = clock64();
+            // The first poll is NOT sent at once: a poll that reaches memory while the other workgroups' write-through stores of the
+            // same lines are still on their way comes back late (and holds up, in order, whatever the wave asks for next); one
+            // that leaves about 0.4 us later finds the words there.  Measured, the whole loop of `cgsolver n out` in us, delay in
+            // units of s_sleep 1 (64 clocks): n = 512 / 1024 / 2048 / 4096: no delay 509 / 685 / 992 / 3134, 8: 382 / 530 / 926 / 3085,
+            // 14: 333 / 497 / 923 / 3068, 16: 330 / 500 / 898 / 3063, 20: 353 / 522 / 910 / 3041, 28: 373 / 557 / 966 / 3070
+            // (profiles/r05_window/poll_delay.txt): 2.8 us per iteration at n = 1024 instead of 3.3-3.9.
+            __builtin_amdgcn_s_sleep(16);
             if (any) {
                 const unsigned long long *watch = slot + 2 * (size_t)xpos(2 * tid);   // column 2 tid: valid whenever `any`
                 for (;;) {
@@ -309,16 +321,24 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
                 any = need != 0;
                 if (any && wall_clock64() - t0 > a.timeout_ticks) expired = true;
             }
-            // what the exchange of this iteration cost, kept only when it took more than one round trip per phase (or for the
-            // launch's first iteration, where a workgroup that was placed late shows): a.rec, resident_record
-            if (tid == 0 && (watch_rounds + gather_rounds > 2 || k == a.k0)) {
-                atomicAdd(lds_rec, (unsigned)(watch_rounds - 1));
-                atomicAdd(lds_rec + 1, (unsigned)(gather_rounds - 1));
-                atomicMax(lds_rec + (k == a.k0 ? 2 : 3), (unsigned)(wall_clock64() - t0));
+            // What the exchange of this iteration cost (ResidentTail): the repeated polls are counted (two LDS adds that nobody waits
+            // for); the span from the publish to the last gathered word is TIMED only when it took several round trips, or in the
+            // launch's first iteration, where a workgroup that was placed late shows -- at n = 1024 the first poll of the watched
+            // word usually comes too early (the exchange takes about two round trips), and a clock read in every iteration was
+            // 0.6 us of 3.2.
+            if (tid == 0) {
+                // (thread 0 is the only one that touches these words: no atomics)
+                if (watch_rounds > 1) lds_rec[0] += (unsigned)(watch_rounds - 1);
+                if (gather_rounds > 1) lds_rec[1] += (unsigned)(gather_rounds - 1);
+                if (watch_rounds + gather_rounds > 6 || k == a.k0) {
+                    const unsigned dt = (unsigned)(wall_clock64() - t0);
+                    unsigned *w = lds_rec + (k == a.k0 ? 2 : 3);
+                    if (dt > *w) *w = dt;
+                }
             }
             if (expired) {
                 atomicExch(a.err, 1);
-                *reinterpret_cast<volatile int *>(lds_fail) = 1;
+                *lds_fail = 1;
             }
         }
 
@@ -330,7 +350,10 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
         v = wave_sum_swap(v);
         if (lane == 0) red[4 * R + wave] = v;
         __syncthreads();
-        if (*reinterpret_cast<volatile int *>(lds_fail)) return;     // uniform: written in front of the barrier
+        if (*lds_fail) {                                             // uniform: written in front of the barrier
+            if (tid == 0) tail_report(a, 1, 0, k, lds_rec);
+            return;
+        }
         const double conj = (red[4 * R] + red[4 * R + 1]) + (red[4 * R + 2] + red[4 * R + 3]);
         const double alpha = safeguarded_alpha(rsold, conj);         // cg.cc:107
         if (prof) tp[4] = clock64();
@@ -395,7 +418,7 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
             sc_out->done = stop;
         }
     }
-    if (tid == 0 && a.rec) resident_record(a.rec, blockIdx.x == 0, k - a.k0 + stop, lds_rec[0], lds_rec[1], lds_rec[2], lds_rec[3]);
+    if (tid == 0) tail_report(a, 0, stop, k, lds_rec);
 }
 
 // a == nullptr: prepare (raise the kernel's dynamic-LDS limit, ask the runtime how many workgroups a CU keeps resident); else launch

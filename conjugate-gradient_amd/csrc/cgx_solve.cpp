@@ -364,22 +364,32 @@ cgx_status resident_steps(cgx_ctx *ctx, int nsteps, int *redo)
         a.tol = ctx->tol;
         a.timeout_ticks = ctx->res_timeout_ticks;
         a.err = ctx->d_res_err;
-        a.rec = ctx->d_res_rec;
+        a.tail = ctx->h_res_tail;
+        a.stamp = ++ctx->res_stamp ? ctx->res_stamp : ++ctx->res_stamp;   // never 0
         a.prof = d_prof;
         a.mute_wg = ctx->res_mute_wg;
         ctx->res_mute_wg = -1;
-        int *flags = ctx->h_flags + 4;
+        const cgx::ResidentTail *tail = ctx->h_res_tail;
         {
             DeviceLock lock(ctx);
             HIP_TRY(ctx, cgx::launch_cg_resident(ctx->rplan, a, ctx->stream));
-            flags[2] = 0;
-            const cgx::Scalars *sc_out = reinterpret_cast<const cgx::Scalars *>(a.out + cgx::state_off_sc(ctx->lda));
-            HIP_TRY(ctx, hipMemcpyAsync(flags, &sc_out->done, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipMemcpyAsync(flags + 2, ctx->d_res_err, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            HIP_TRY(ctx, hipMemcpyAsync(ctx->h_res_rec, ctx->d_res_rec, 8 * sizeof(long long), hipMemcpyDeviceToHost, ctx->stream));
+            // no copy command: the kernel has written its report into pinned memory itself, the launch's stamp last
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         }
-        memcpy(ctx->res_rec, ctx->h_res_rec, sizeof ctx->res_rec);
+        const bool reported = tail->stamp == a.stamp;   // (always, once the kernel has ended; anything else is treated as a failed launch)
+        if (reported) {
+            ctx->res_rec[0] += tail->iterations;
+            ctx->res_rec[1] += tail->watch_repeats;
+            ctx->res_rec[2] += tail->gather_repeats;
+            ctx->res_rec[3] += 1;
+            ctx->res_rec[4] = std::max<long long>(ctx->res_rec[4], tail->waits[0][0]);
+            ctx->res_rec[5] = std::max<long long>(ctx->res_rec[5], tail->waits[0][1]);
+            for (int g = 0; g < ctx->rplan.grid && g < 256; ++g) {
+                ctx->res_rec[6] = std::max<long long>(ctx->res_rec[6], tail->waits[g][0]);
+                ctx->res_rec[7] = std::max<long long>(ctx->res_rec[7], tail->waits[g][1]);
+            }
+        }
+        int flags[3] = {reported ? tail->done : 0, reported ? tail->k_final : 0, reported ? tail->err : 1};
         if (flags[2]) {
             // A wait for another workgroup's Ap expired: the grid was not resident at once.  Epochs that may have been used:
             ctx->res_epoch += (unsigned long long)batch;
@@ -462,6 +472,23 @@ cgx_status cgx_solve_begin(cgx_ctx *ctx, const double *x0)
     hipStream_t st = ctx->stream;
     const int n = ctx->n;
     const size_t vec_bytes = (size_t)ctx->lda * sizeof(double);
+    memset(ctx->res_rec, 0, sizeof ctx->res_rec);
+    // A persistent solve from a zero initial guess (what the reference's main passes, cg_main.cc:48-50): everything below in
+    // ONE kernel -- r = b - A 0 = b needs no GEMV.  With the persistent launch, the verification GEMV and the one-kernel
+    // end (cgx_solve_end) the whole solve() is four launches and no copy command.
+    ctx->lean = false;
+    if (ctx->resident && ctx->h_stage && ctx->shards.size() == 1 && ctx->shards[0].state[0]) {
+        bool zero = true;
+        for (int i = 0; i < n && zero; ++i) zero = x0[i] == 0.0 && !std::signbit(x0[i]);
+        if (zero) {
+            Shard &s = ctx->shards[0];
+            HIP_TRY(ctx, cgx::launch_solve_begin_zero(n, ctx->lda, s.b_full, s.x, s.rv, s.p[0], s.p[1], s.apg,
+                                                      (long)ctx->nranks * ctx->seg_S, s.sc, ctx->d_res_err, st));
+            ctx->lean = true;
+            ctx->in_solve = true;
+            return CGX_OK;
+        }
+    }
     const double *x_src = x0;
     if (ctx->h_stage) {
         memcpy(ctx->h_stage, x0, (size_t)n * sizeof(double));
@@ -486,12 +513,7 @@ cgx_status cgx_solve_begin(cgx_ctx *ctx, const double *x0)
         HIP_TRY(ctx, hipMemsetAsync(s.p[0], 0, vec_bytes, st));
         HIP_TRY(ctx, hipMemsetAsync(s.p[1], 0, vec_bytes, st));
     }
-    if (ctx->resident) {
-        // a solve starts with the error word down and an empty record of what its waits cost
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_res_err, 0, sizeof(int), st));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->d_res_rec, 0, 8 * sizeof(long long), st));
-        memset(ctx->res_rec, 0, sizeof ctx->res_rec);
-    }
+    if (ctx->resident) HIP_TRY(ctx, hipMemsetAsync(ctx->d_res_err, 0, sizeof(int), st));   // a solve starts with the error word down
     ctx->in_solve = true;
     return CGX_OK;
 }
@@ -567,6 +589,35 @@ cgx_status cgx_solve_end(cgx_ctx *ctx, double *x, cgx_result *res)
         CGX_TRY(read_flags_sync(ctx));
     }   // (resident: done / k_final were read behind the last launch, resident_steps; one host synchronisation less)
     const int k_exit = ctx->done ? ctx->k_final : ctx->k;
+
+    if (ctx->lean && ctx->resident && ctx->k > 0) {
+        // The persistent path's end in two launches: x lies whole in the current state block (one GPU: every row is this shard's,
+        // the pad columns are zero), so the verification GEMV (cg.cc:146-147) takes it as it is, and ONE kernel does the DEBUG
+        // norms (cg.cc:148-151) and puts x, the three sums and rs[] into the pinned buffer.
+        Shard &s = ctx->shards[0];
+        CGX_TRY(run_gemv_plain(ctx, s, s.x));
+        HIP_TRY(ctx, cgx::launch_solve_end(ctx->n, s.Ap(), s.b_full, s.x, s.sc, ctx->h_stage, st));
+        HIP_TRY(ctx, hipStreamSynchronize(st));
+        const double *o = ctx->h_stage + ctx->n;
+        if (x) memcpy(x, ctx->h_stage, (size_t)ctx->n * sizeof(double));
+        ctx->in_solve = false;
+        ctx->lean = false;
+        if (res) {
+            memset(res, 0, sizeof *res);
+            res->iterations = k_exit;
+            res->converged = ctx->done ? 1 : 0;
+            res->residual_prev = std::sqrt(o[3 + (k_exit & 1)]);           // sqrt(rsold) as printed, cg.cc:152-153
+            res->residual_last = std::sqrt(o[3 + ((k_exit + 1) & 1)]);
+            if (!ctx->done) res->residual_last = res->residual_prev;        // loop ran out: rsold == rsnew (cg.cc:132)
+            res->x_norm = std::sqrt(o[2]);
+            res->rel_residual = std::sqrt(o[0]) / std::sqrt(o[1]);
+            res->seconds_solve = wall_now() - ctx->t_begin;
+            res->seconds_loop = ctx->t_loop;
+            res->gemv_bytes = 8.0 * ((double)s.rows * ctx->n + ctx->n + s.rows);
+        }
+        return CGX_OK;
+    }
+    ctx->lean = false;
 
     // Gather x (MPI_Gatherv, cg.cc:140-142) through the exchange segments, then the DEBUG verification
     // (cg.cc:144-151) with the same K1, distributed over the shards instead of rank 0 alone.

@@ -99,7 +99,10 @@ __global__ __launch_bounds__(kStrThreads, 2) void k_cg_stream(ResidentArgs a)
 
     if (tid == 0) *lds_fail = 0;
     if (tid < 4) lds_rec[tid] = 0;
-    if (__syncthreads_or(__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) return;
+    if (__syncthreads_or(__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+        if (tid == 0) tail_report(a, 1, 0, a.k0, nullptr);
+        return;
+    }
 
     // A through a buffer descriptor that spans the matrix: row i of the workgroup, column step s = scalar offset (row0 + i) pitch
     // + 8 KB s, the thread's column pair = ONE 32-bit byte offset (a second one for the last column step, whose pair may lie
@@ -294,12 +297,18 @@ __global__ __launch_bounds__(kStrThreads, 2) void k_cg_stream(ResidentArgs a)
                     lds_ap[s * T + tid] = g;
                 }
             }
-            // what the exchange of this iteration cost, kept only when a poll had to be repeated (or for the launch's first
-            // iteration, where a workgroup that was placed late shows): a.rec, resident_record
-            if (tid == 0 && (wr + gr > 1 || k == a.k0)) {
-                atomicAdd(lds_rec, (unsigned)(wr - 1));
-                atomicAdd(lds_rec + 1, (unsigned)gr);
-                atomicMax(lds_rec + (k == a.k0 ? 2 : 3), (unsigned)(wall_clock64() - t0));
+            // what the exchange of this iteration cost (ResidentTail): repeated polls are counted; the span from the publish to the
+            // last gathered word is timed when it took several round trips, or in the launch's first iteration (a workgroup that
+            // was placed late shows there)
+            if (tid == 0) {
+                // (thread 0 is the only one that touches these words: no atomics)
+                if (wr > 1) lds_rec[0] += (unsigned)(wr - 1);
+                if (gr > 0) lds_rec[1] += (unsigned)gr;
+                if (wr + gr > 5 || k == a.k0) {
+                    const unsigned dt = (unsigned)(wall_clock64() - t0);
+                    unsigned *w = lds_rec + (k == a.k0 ? 2 : 3);
+                    if (dt > *w) *w = dt;
+                }
             }
             if (stamp) {
                 pst[2] = wall_clock64();
@@ -314,7 +323,10 @@ __global__ __launch_bounds__(kStrThreads, 2) void k_cg_stream(ResidentArgs a)
         pap = wave_sum_swap(pap);
         if (lane == 0) dot[wave] = pap;
         lds_barrier();
-        if (*lds_fail) return;         // uniform: written in front of the barrier
+        if (*lds_fail) {               // uniform: written in front of the barrier
+            if (tid == 0) tail_report(a, 1, 0, k, lds_rec);
+            return;
+        }
         const double conj = ((dot[0] + dot[1]) + (dot[2] + dot[3])) + ((dot[4] + dot[5]) + (dot[6] + dot[7]));
         const double alpha = safeguarded_alpha(rsold, conj);             // cg.cc:107
         double rr = 0.0;
@@ -377,7 +389,7 @@ __global__ __launch_bounds__(kStrThreads, 2) void k_cg_stream(ResidentArgs a)
             sc_out->done = stop;
         }
     }
-    if (tid == 0 && a.rec) resident_record(a.rec, blockIdx.x == 0, k - a.k0 + stop, lds_rec[0], lds_rec[1], lds_rec[2], lds_rec[3]);
+    if (tid == 0) tail_report(a, 0, stop, k, lds_rec);
     // the ring's last loads (the rows of an iteration that never comes) are simply dropped with the wave
 }
 

@@ -4,6 +4,7 @@
 #pragma once
 
 #include "cgx_device.h"
+#include "cgx_kernels.h"
 
 namespace cgx {
 
@@ -128,28 +129,25 @@ __device__ __forceinline__ double tagged_value(const u4 &w)
     return __longlong_as_double((long long)((unsigned long long)w.x | ((unsigned long long)w.z << 32)));
 }
 
-// What the waits of a launch cost (ResidentArgs::rec, 8 x 64 bits, zeroed by the host when a solve begins; cgx_get_resident_record,
-// cgsolver --stats): thread 0 of every workgroup keeps four LDS words during the launch and calls this once at its end.
-//   [0] iterations run (workgroup 0)   [1] polls of the watched word that had to be REPEATED (workgroup 0)   [2] gather rounds
-//   that had to be repeated (workgroup 0)   [3] launches   [4] workgroup 0: wall-clock ticks (100 MHz) from its publish of the
-//   launch's FIRST iteration until it had gathered all of Ap -- a workgroup of the grid that was placed late shows here --,
-//   largest over the launches   [5] workgroup 0: the longest such span of any LATER iteration in which a poll had to be repeated
-//   (the exchange itself; 0 = none ever was)   [6], [7] the same two, largest over ALL workgroups (one atomic max each per
-//   workgroup and launch).  An iteration whose polls all succeed at once is not timed: one round trip is the price of the
-//   exchange, not a wait.
-__device__ __forceinline__ void resident_record(long long *rec, bool wg0, long long iters, long long wrounds, long long grounds,
-                                                long long wait_first, long long wait_max)
+// A workgroup's report at the end of a persistent launch (ResidentTail, cgx_kernels.h), thread 0 only.  `rec` = the four LDS
+// words it kept during the launch: polls of the watched word that had to be repeated, gather rounds that had to be repeated, ticks
+// from its publish of the launch's first iteration until it had all of Ap, the longest such span of a later iteration in which
+// a poll had to be repeated.  An iteration whose polls all succeed at once is not timed: one round trip is the price of the
+// exchange, not a wait.
+__device__ __forceinline__ void tail_report(const ResidentArgs &a, int err, int stop, int k, const unsigned *rec)
 {
-    if (wg0) {
-        rec[0] += iters;
-        rec[1] += wrounds;
-        rec[2] += grounds;
-        rec[3] += 1;
-        if (wait_first > rec[4]) rec[4] = wait_first;
-        if (wait_max > rec[5]) rec[5] = wait_max;
+    ResidentTail *t = a.tail;
+    t->waits[blockIdx.x][0] = rec ? rec[2] : 0u;
+    t->waits[blockIdx.x][1] = rec ? rec[3] : 0u;
+    if (blockIdx.x == 0) {
+        t->done = stop;
+        t->k_final = stop ? k : 0;
+        t->err = err;
+        t->iterations = k - a.k0 + stop;
+        t->watch_repeats = rec ? rec[0] : 0u;
+        t->gather_repeats = rec ? rec[1] : 0u;
+        t->stamp = a.stamp;
     }
-    atomicMax(reinterpret_cast<unsigned long long *>(rec + 6), (unsigned long long)wait_first);
-    atomicMax(reinterpret_cast<unsigned long long *>(rec + 7), (unsigned long long)wait_max);
 }
 
 // LDS hand-off between the waves of a workgroup WITHOUT draining the wave's global loads: __syncthreads() is a workgroup-scope

@@ -576,7 +576,7 @@ def test_error_paths_of_a_resident_solve(gpu_pkg, n):
                 failures += 1
             s._set_fault_after(-1)
             assert abs(free_mb() - base) < 2, k
-        assert failures >= 10 and np.array_equal(x, x_good)
+        assert failures >= 5 and np.array_equal(x, x_good)      # (a solve from a zero initial guess is four launches and two synchronisations)
         x = np.zeros(n)
         s.solve(x)
         assert np.array_equal(x, x_good)
