@@ -264,13 +264,16 @@ def cpu_baseline(n, iters):
 
 
 def reference_sizes(pkg, torch):
-    """The reference's own experiment sizes (code/MPI/cg.run:15-44: N = 1024, 2048, 4096 ... to convergence or 200 iterations) on this
-    GPU: iterations/s of the loop with the library's default (the LDS-resident persistent kernel) and with
-    the per-launch path (K1 + K3 per iteration), tol = 0, 2000 timed iterations after 200, best of 3.  Not the headline metric."""
+    """The reference's own experiment sizes (code/MPI/cg.run:15-44: N = 1024, 2048, 4096, 8192 ... to convergence or 200 iterations)
+    and BASELINE.json configs[1]'s N = 10000 on this GPU: iterations/s of the loop with the library's default (n <= 4096: the resident
+    persistent kernel; n <= 8192: the streaming persistent kernel, section 4c; above: K1 + K3) and with the
+    per-launch path (K1 + K3 per iteration), tol = 0, timed iterations after 200, best of 3; `hbm_roofline_frac` = the whole
+    iteration against the GEMV's algorithmic bytes 8 (n^2 + 2 n) at 8 TB/s.  Not the headline metric."""
     import numpy as np
     rows = []
-    for n in (1024, 2048, 4096):
+    for n in (1024, 2048, 4096, 8192, 10000):
         row = {"n": n}
+        steps = 2000 if n <= 4096 else 600
         for name, variant in (("default", 0), ("per_launch", -1)):
             with pkg.CGSolver(gemv_variant=variant) as s:
                 s.generate_lap2d_matrix(n)
@@ -284,12 +287,13 @@ def reference_sizes(pkg, torch):
                 for _ in range(3):
                     torch.cuda.synchronize()
                     t0 = time.perf_counter()
-                    s.solve_steps(2000)
-                    best = min(best, (time.perf_counter() - t0) / 2000)
+                    s.solve_steps(steps)
+                    best = min(best, (time.perf_counter() - t0) / steps)
                 s.solve_end()
             row[name] = {"iterations_per_s": 1.0 / best, "us_per_iteration": best * 1e6,
+                         "hbm_roofline_frac": 8.0 * (n * n + 2 * n) / best / (HBM_PEAK_GBS * 1e9),
                          "kernel": ("one persistent kernel, A in LDS" + (" + registers + streamed rest" if plan["light"] else ""))
-                         if plan["variant"] == 4 else "K1 + K3 per iteration"}
+                         if plan["variant"] == 4 else "one persistent kernel, A streamed" if plan["variant"] == 5 else "K1 + K3 per iteration"}
         rows.append(row)
     return rows
 

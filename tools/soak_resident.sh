@@ -1,5 +1,5 @@
 #!/bin/bash
-# Soak of the LDS-resident solver on one MI355X: a long randomised sweep (tools/fuzz_resident.py) and two runs of ONE solve of
+# LIVENESS soak (NaN payload; the finite soak is tools/soak_finite.py) of the LDS-resident solver on one MI355X: a long randomised sweep (tools/fuzz_resident.py) and two runs of ONE solve of
 # 15 M iterations each (tol = 0, n = 1024: 229 launches of 65 536 iterations, ~50 s) that must agree bit for bit.  (Far behind
 # convergence rsold underflows to 0 and alpha = 0/0, cg.cc:107, as in the reference: from then on the payload of the exchange
 # is NaN -- this run soaks the exchange and its tags, 15 M epochs per run, not the arithmetic.)
