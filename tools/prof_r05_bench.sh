@@ -18,7 +18,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmcb_$c -- python3 $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-live-pmc > /tmp/pmcb_$c.json 2> /tmp/pmcb_$c.log
   python3 - "$(find /tmp/pmcb_$c -name '*counter_collection.csv' | head -1)" $c $OUT/bench20_${c}_counter_collection.csv <<'PY'
 import csv, sys
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_gemv_colsplit" in r["Kernel_Name"] and ", 1, " in r["Kernel_Name"] and r["Counter_Name"] == sys.argv[2]]
+# the timed region's kernel only (the line's reference_sizes leg launches fused K1s of other shapes as well): 4096 workgroups x 256
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "k_gemv_colsplit<8, 2, 4, 1, false, true>" in r["Kernel_Name"] and r["Grid_Size"] == "1048576" and r["Counter_Name"] == sys.argv[2]][:64]
 with open(sys.argv[3], "w", newline="") as fh:
     w = csv.DictWriter(fh, fieldnames=list(rows[0].keys())); w.writeheader(); w.writerows(rows)
 v = [float(r["Counter_Value"]) for r in rows]
