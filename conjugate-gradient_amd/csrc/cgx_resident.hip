@@ -43,6 +43,14 @@ namespace cgx {
 
 namespace {
 
+#ifndef CGX_RES_STREAM_POLICY
+// The streamed rows' cache policy: the DEFAULT one, not nt.  What is streamed is at most 4 rows x 256 workgroups x 32 KB = 32 MiB
+// per iteration, 4 MiB per XCD -- the size of an XCD's L2 -- and the same bytes every iteration: with the default policy part
+// of them is still in the L2 an iteration later (7.51 -> 5.99 us per iteration at n = 4096, 5.03 -> 4.84 at 3584; sc0 / sc1 the
+// same; profiles/r05_mall/, tools/exp_mall_policy.sh builds the others).  cgx_stream.hip's rows pass once per iteration through
+// caches they do not fit: nt there (default policy: 92 instead of 79 us at n = 8192).
+#define CGX_RES_STREAM_POLICY ""
+#endif
 constexpr int kResThreads = 256;
 
 
@@ -50,7 +58,7 @@ constexpr int kResThreads = 256;
 // Where a workgroup's rows live.  n <= 2048: all R <= 8 rows in LDS.  2048 < n <= 4096: the matrix (up to 128 MiB) no longer
 // fits the LDS alone -- but a CU also has a 512 KB register file, and a workgroup of 256 threads at one per CU may use all of
 // it: R = 16 rows per workgroup, RL rows in LDS, RG rows in REGISTERS (thread t holds its own 2 S columns of each: 4 S registers
-// per row, loaded once per launch), and the remaining RS rows streamed from memory every iteration (non-temporal 16-byte loads,
+// per row, loaded once per launch), and the remaining RS rows streamed from memory every iteration (16-byte loads, default cache policy,
 // two rows per batch, the first batch of an iteration issued right behind the gather of the previous one).
 // S = 5: 7 + 9 + 0 (all resident, n <= 2560); S = 6: 6 + 10 + 0 (all resident, n <= 3072); S = 7: 5 + 9 + 2;
 // S = 8: 4 + 8 + 4 (n = 4096: 32 of 128 MiB re-read per iteration).
@@ -114,7 +122,7 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
     auto stream_issue = [&](int i, int s) {
         const double *row = row_ptr(i);
         d2 v;
-        asm volatile("global_load_dwordx4 %0, %1, %2 nt" : "=v"(v) : "v"(soff[s]), "s"(row) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, %2" CGX_RES_STREAM_POLICY : "=v"(v) : "v"(soff[s]), "s"(row) : "memory");
         return v;
     };
 

@@ -45,7 +45,10 @@ namespace {
 constexpr int kStrThreads = 512, kStrWaves = 8;
 
 typedef __amdgpu_buffer_rsrc_t rsrc_t;
-constexpr int kAuxNt = 2;                        // nt: streamed once, do not keep
+#ifndef CGX_STREAM_AUX
+#define CGX_STREAM_AUX 2
+#endif
+constexpr int kAuxNt = CGX_STREAM_AUX;           // 2 = nt: streamed once, do not keep (tools/exp_mall_policy.sh builds the others)
 constexpr int kAuxSc1 = 16;                      // sc1: agent scope (loads past the L1, stores written through)
 // (a poll is an sc1 load as well; what makes the compiler re-issue it every time round a loop is the `asm volatile("" ::: "memory")`
 // in front of it -- the intrinsic's own volatile bit would turn it into a system-scope sc0 sc1 load)

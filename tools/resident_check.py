@@ -10,7 +10,7 @@ import __graft_entry__ as g
 pkg = g.load_package()
 from oracle import oracle
 
-sizes = [int(v) for v in os.environ.get("SIZES", "2,7,64,300,512,513,1000,1024,1448,2047,2048,2049,2896,3072,3584,4096").split(",")]
+sizes = [int(v) for v in os.environ.get("SIZES", "2,7,64,300,512,513,1000,1024,1448,2047,2048,2049,2896,3072,3584,4096").split(",") if v]
 timing = [int(v) for v in os.environ.get("TIMING", "256,512,1024,1448,2048,2560,2896,3072,3584,4096").split(",")]
 out = []
 for n in sizes:
