@@ -22,9 +22,10 @@ using namespace cgxi;
 namespace cgxi {
 
 // Largest n the DEFAULT choice hands to the streaming persistent kernel: measured against the per-launch path it wins up to
-// N = 8192 (31.7 / 44.7 / 78.7 us per iteration at N = 5120 / 6144 / 8192 against 35.7 / 47.8 / 79.8) and loses above (122 against
-// 119 at N = 10000): with equal static shares a sweep ends with its slowest workgroup
-constexpr int kStreamDefaultMax = 8192;
+// N = 9216 (20.3 / 34.8 / 54.4 / 76.2 / 96.9 us per iteration at N = 5120 / 6144 / 7168 / 8192 / 9216 against 36.3 / 48.3 / 66.0 /
+// 80.3 / 105.8) and ties above (119.6 against 119.4-120.4 at N = 10000, where no row of A fits on the chip beside the vectors:
+// DESIGN.md section 4c)
+constexpr int kStreamDefaultMax = 9216;
 
 thread_local std::string g_create_error;
 

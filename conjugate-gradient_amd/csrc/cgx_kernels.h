@@ -296,6 +296,7 @@ struct ResidentArgs {
     double tol;
     long long timeout_ticks;    // bound of every wait, 100 MHz wall-clock ticks
     int *err;          // device word raised when a wait expired
+    int stagger;       // streaming kernel: every workgroup begins its sweep at a batch of its own (0 = all at their first rows)
     int mute_wg;       // test only (cgx_probe_resident_test): this workgroup leaves out the publish of the launch's first iteration; -1 = none
     ResidentTail *tail;   // PINNED HOST memory: what the launch reports back (written by the kernel itself: no copy command)
     unsigned stamp;    // the launch's number (never 0): workgroup 0's last word into the tail

@@ -367,6 +367,10 @@ cgx_status resident_steps(cgx_ctx *ctx, int nsteps, int *redo)
         a.tail = ctx->h_res_tail;
         a.stamp = ++ctx->res_stamp ? ctx->res_stamp : ++ctx->res_stamp;   // never 0
         a.prof = d_prof;
+        {
+            static const int stagger = [] { const char *e = getenv("CGX_STREAM_STAGGER"); return e ? atoi(e) : 1; }();
+            a.stagger = stagger;
+        }
         a.mute_wg = ctx->res_mute_wg;
         ctx->res_mute_wg = -1;
         const cgx::ResidentTail *tail = ctx->h_res_tail;

@@ -6,10 +6,14 @@
 // and what an iteration loses is everything around K1: the update kernel K3 (4.8-5.0 us of latency chain), two kernel
 // boundaries and two launch ramps -- 6-7 % of an 80 us iteration at N = 8192.  This kernel keeps cgx_resident.hip's structure
 // (r and p replicated in every workgroup, Ap exchanged as tagged words, no K3, no kernel boundary, no grid barrier) and
-// streams ALL rows:
+// streams the rows -- all but the few that the chip holds beside the vectors:
 //
 //   grid  = G <= 256 workgroups of 512 threads (8 waves, 2 per SIMD, up to 256 registers each), one per CU, all resident;
-//           workgroup g owns the R = ceil(n / 256) (rounded up to the batch) consecutive rows g R ... g R + R - 1;
+//           workgroup g owns the R consecutive rows g R ... g R + R - 1, R = ceil(n / 256) rounded up so that the streamed
+//           rows are a whole number of batches; its first RL rows are copied into the LDS and the next RG into registers once
+//           per launch (the thread keeps the pairs it multiplies), the other R - RL - RG are streamed every iteration:
+//           S = 5 (n <= 5120): 2 + 6 of 20 rows; S = 6: 2 + 4 of 24; S = 7: 1 + 3 of 28; S = 8 (n <= 8192): 1 + 1 of 32;
+//           S = 9: 1 + 1 of 36; above: none (the LDS holds the parked Ap, 8 KB S, and nothing else of that size);
 //   state = r, p in registers, replicated in every workgroup: thread t owns the column pairs {1024 s + 2 t, + 1}, s < S =
 //           ceil(n / 1024) -- the same columns whose entries of A it streams, so the GEMV needs no vector traffic at all;
 //   A     = streamed through a RING of RB x S 16-byte registers per thread (RB rows of the thread's columns): a slot is
@@ -19,12 +23,14 @@
 //           builtins, so every wait on streamed data is the compiler's own vmcnt bookkeeping (no hand-written waits: ADVICE r4).  The rows do not depend on p, so the ring simply
 //           wraps around: while the workgroups exchange Ap and update r and p, the first RB rows of the NEXT iteration are
 //           already in flight (128 KB per CU at N = 8192) and the memory pipe does not run dry across the iteration boundary;
+//           every workgroup begins its sweep at a batch of its own (phi, below: 256 streams in step meet in the same memory
+//           channels for some row pitches otherwise);
 //   one iteration (cg.cc:96-137) =
 //     Ap_sub = A_sub p            every wave sweeps its 128 columns of each 1024-column step of every row; per batch of RB rows
 //                                 one wave reduction (v_permlane swaps + DPP), per row 8 wave partials in LDS    cg.cc:100-102
 //     publish Ap_sub              R tagged doubles per workgroup (cgx_tagged.h)
 //     gather Ap                   every thread polls one watched word, then the tagged words of its 2 S columns in chunks of
-//                                 <= 8 (agent-scope buffer loads: one 32-bit lane offset, parity and column step scalar)
+//                                 4 (agent-scope buffer loads: one 32-bit lane offset, parity and column step scalar)
 //     p.Ap, alpha, x, r, r.r, break test, beta, p: as cgx_resident.hip, every workgroup over the whole vectors, same order:
 //                                 bit-identical everywhere                                                         cg.cc:105-132
 //
@@ -52,6 +58,12 @@ constexpr int kAuxNt = CGX_STREAM_AUX;           // 2 = nt: streamed once, do no
 constexpr int kAuxSc1 = 16;                      // sc1: agent scope (loads past the L1, stores written through)
 // (a poll is an sc1 load as well; what makes the compiler re-issue it every time round a loop is the `asm volatile("" ::: "memory")`
 // in front of it -- the intrinsic's own volatile bit would turn it into a system-scope sc0 sc1 load)
+
+// a value every lane holds alike, moved into scalar registers (two of them instead of two vector registers per lane)
+__device__ __forceinline__ double uniform(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
 
 __device__ __forceinline__ d2 as_d2(u4 w) { return __builtin_bit_cast(d2, w); }
 __device__ __forceinline__ bool tag_ok(const u4 &w, unsigned tag) { return ((w.y ^ tag) | (w.w ^ tag)) == 0; }
@@ -82,13 +94,18 @@ __device__ __forceinline__ int batch_sum(double (&v)[RB], int lane)
 // sums are reduced together); CH = column steps per gather chunk (2 CH tagged words in flight per thread).
 // Registers (hipcc 7.2, tools/kernel_resources.py): p and r 8 S, the ring 4 RB S, a gather chunk 8 CH; the gathered Ap is
 // parked in LDS between p.Ap and the update of r (8 KB per column step), so it costs none.
-template <int S, int RB, int CH>
+// RL + RG of a workgroup's rows (its first ones) do not stream: RL are copied into the LDS and RG into registers once per launch
+// (what the LDS holds beside the parked Ap, what the 256 registers of a thread hold beside r, p and the ring: stream_rl / stream_rg).
+template <int S, int RB, int CH, int RL, int RG>
 __global__ __launch_bounds__(kStrThreads, 2) void k_cg_stream(ResidentArgs a)
 {
     constexpr int T = kStrThreads, W = kStrWaves;
+    constexpr int RES = RL + RG;                                       // rows on the chip
+    constexpr int RESP = RES <= 1 ? 1 : RES <= 2 ? 2 : RES <= 4 ? 4 : 8;   // ... their sums are reduced together: a power of two
+    static_assert(RES <= 8, "at most 8 rows on the chip");
     extern __shared__ double lds_all[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = a.n, R = a.rows_per_wg, nb = R / RB;
+    const int n = a.n, R = a.rows_per_wg, nb = (R - RES) / RB;
     double *lds_red = lds_all;                        // [W][R]: the waves' parts of the row sums
     double *lds_dot = lds_red + W * R;                // two sets of [p.Ap | r.r] x W wave partials
     double *lds_sum = lds_dot + 4 * W;                // W doubles for the set-up's block sum
@@ -97,6 +114,8 @@ __global__ __launch_bounds__(kStrThreads, 2) void k_cg_stream(ResidentArgs a)
     int *lds_fail = reinterpret_cast<int *>(lds_sum + W);
     unsigned *lds_rec = reinterpret_cast<unsigned *>(lds_fail) + 2;   // thread 0: [watch rounds | repeated gather rounds | first wait | longest later wait] (a.rec)
     d2 *lds_ap = reinterpret_cast<d2 *>(lds_sum + W + 4);   // [S][T] pairs: the gathered Ap of this thread's columns
+    d2 *lds_A = lds_ap + S * T;                             // [RL][S][T] pairs: the rows kept in the LDS
+    d2 *lds_own = lds_A + RL * S * T;                       // [3][R / 2 + 2] pairs: x, r, p of the workgroup's own rows
     const int row0 = blockIdx.x * R;
     const int my_rows = min(R, n - row0);             // >= 1 by construction of the grid
 
@@ -127,6 +146,18 @@ __global__ __launch_bounds__(kStrThreads, 2) void k_cg_stream(ResidentArgs a)
     // the exchange buffer: [2 parities][1024 S tagged doubles of 16 bytes]
     const rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, 2 * a.xslots * 16, 0x00020000);
 
+    // the rows on the chip: the workgroup's first RL into the LDS, the next RG into registers (once per launch; the thread keeps
+    // exactly the pairs it multiplies: nobody else reads them, no barrier)
+    d2 areg[RG > 0 ? RG : 1][S];
+#pragma unroll
+    for (int i = 0; i < RL; ++i)
+#pragma unroll
+        for (int s = 0; s < S; ++s) lds_A[(i * S + s) * T + tid] = a_issue(i, s);
+#pragma unroll
+    for (int i = 0; i < RG; ++i)
+#pragma unroll
+        for (int s = 0; s < S; ++s) areg[i][s] = a_issue(RL + i, s);
+
     // The ring.  It is FILLED by the sweep loop itself (a batch -1 in front of the launch's first iteration: FMAs on zeros, its
     // row sums dropped), not by loads in front of the loop: the compiler's wait in front of a slot is exact (vmcnt(RB S - 1):
     // every other slot stays in flight) only when the loads it counts reach the loop's head in ONE order -- with a separate
@@ -136,16 +167,23 @@ __global__ __launch_bounds__(kStrThreads, 2) void k_cg_stream(ResidentArgs a)
     for (int j = 0; j < RB; ++j)
 #pragma unroll
         for (int s = 0; s < S; ++s) ring[j][s] = d2{0.0, 0.0};
-    int b_first = -1;
+    int b_first = -1, pcur = 0;
+    // where this workgroup begins its sweep: a batch of its own (a hash of the workgroup's number).  The workgroups sweep in step, and
+    // with all of them at the same place in their rows the 256 streams lie multiples of R x pitch apart -- for some pitches
+    // in the same memory channels (N = 8192, pitch + 512 B: 102 instead of 75 us; N = 8704, + 256 B: 109 instead of 87).  The
+    // regular patterns tried each have such a pitch; the hash had none in 30 combinations (profiles/r05_stagger/README.md).
+    const int phi = a.stagger ? (int)(((unsigned)blockIdx.x * 2654435761u >> 16) % (unsigned)nb) : 0;
 
     // ---- state: r, p for this thread's columns (replicated in every workgroup; exactly 0 in the pad columns n ... 1024 S,
     // where the gathered Ap is a published 0 as well: no masks inside the loop); x for the workgroup's own rows only
     const double *st_x = a.in, *st_r = a.in + state_off_r(a.lda), *st_p = a.in + state_off_p(a.lda);
     const Scalars *st_sc = reinterpret_cast<const Scalars *>(a.in + state_off_sc(a.lda));
     d2 r[S], p[S];
-    // x of the workgroup's own rows: the thread whose column pair lies in them keeps x and a second copy (rx, px) of its r and p
-    // pair, advanced by the same operations (same bits): the update needs no "is this my column step" test per step then
-    d2 xo = {0.0, 0.0}, rx = {0.0, 0.0}, px = {0.0, 0.0};
+    // x of the workgroup's own rows: the thread whose column pair lies in them keeps x and a second copy of its r and p pair,
+    // advanced by the same operations (same bits): the update needs no "is this my column step" test per step then.  The three
+    // pairs live in the LDS (own[0 | 1 | 2][pair index - row0 / 2] = x | r | p; R / 2 + 1 pairs at most): 12 registers of every thread
+    // for something a handful of threads touch twice per iteration would cost a row of A on the chip
+    const int own_n = R / 2 + 2;
     int sx = -1;
     bool ox0 = false, ox1 = false;
 #pragma unroll
@@ -166,13 +204,18 @@ __global__ __launch_bounds__(kStrThreads, 2) void k_cg_stream(ResidentArgs a)
             sx = s;
             ox0 = own0;
             ox1 = own1;
+            d2 xo = {0.0, 0.0};
             if (own0) xo.x = st_x[c];
             if (own1) xo.y = st_x[c + 1];
-            rx = r[s];
-            px = p[s];
+            const int q = T * s + tid - (row0 >> 1);
+            lds_own[q] = xo;
+            lds_own[own_n + q] = r[s];
+            lds_own[2 * own_n + q] = p[s];
         }
     }
     const int ap_own = (sx < 0 ? 0 : sx) * T + tid;   // where the gathered Ap of the owned pair is parked
+    const bool owner = sx >= 0;
+    d2 *own = lds_own + (owner ? ap_own - (row0 >> 1) : 0);
     double rsold, rs_prev;
     if (a.k0 > 0) {
         rsold = st_sc->rs[a.k0 & 1];
@@ -184,6 +227,8 @@ __global__ __launch_bounds__(kStrThreads, 2) void k_cg_stream(ResidentArgs a)
         rsold = block_sum<W>(v, lds_sum);
         rs_prev = rsold;
     }
+    rsold = uniform(rsold);     // (the same bits in every lane: kept in scalar registers across the sweep)
+    rs_prev = uniform(rs_prev);
 
     // Every load of the state has landed before the loop is entered (a real s_waitcnt, which the compiler's bookkeeping sees): with
     // p possibly still in flight from a branch in front of the loop, the loop's FIRST use of p was a vmcnt(0) in every batch,
@@ -222,7 +267,12 @@ __global__ __launch_bounds__(kStrThreads, 2) void k_cg_stream(ResidentArgs a)
         // every slot of the ring is re-issued for the batch after this one as soon as it has been consumed (the fence pins
         // that order: loads return in order, so the wait in front of slot q leaves the other RB S - 1 in flight)
         for (int b = b_first; b < nb; ++b) {
-            const int nxt = (b + 1 < nb) ? (b + 1) * RB : 0;      // behind the last batch: the first one of the next iteration
+            // the batch behind this one (behind the last: the first one of the next iteration), counted from the workgroup's own
+            // first batch phi: the workgroups sweep in step, and with every one of them at the same place in its rows the streams
+            // meet in the same memory channels for some row pitches (profiles/r05_stagger/)
+            int pn = ((b + 1 < nb) ? b + 1 : 0) + phi;
+            if (pn >= nb) pn -= nb;
+            const int nxt = RES + pn * RB;
             double v[RB];
 #pragma unroll
             for (int j = 0; j < RB; ++j) {
@@ -238,9 +288,31 @@ __global__ __launch_bounds__(kStrThreads, 2) void k_cg_stream(ResidentArgs a)
                 v[j] = s0 + s1;
             }
             const int myrow = batch_sum<RB>(v, lane);
-            if (b >= 0 && (lane & (64 / RB - 1)) == 0) lds_red[wave * R + b * RB + myrow] = v[0];
+            if (b >= 0 && (lane & (64 / RB - 1)) == 0) lds_red[wave * R + RES + pcur * RB + myrow] = v[0];
+            pcur = pn;
         }
         b_first = 0;
+        // the rows on the chip, with the first batch of the next iteration already on its way
+        if constexpr (RES > 0) {
+            double v[RESP];
+#pragma unroll
+            for (int j = 0; j < RESP; ++j) {
+                double s0 = 0.0, s1 = 0.0;
+                if (j < RES) {
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        d2 av;
+                        if (j < RL) av = lds_A[(j * S + s) * T + tid];
+                        else av = areg[j < RL ? 0 : j - RL][s];
+                        s0 = fma(av.x, p[s].x, s0);
+                        s1 = fma(av.y, p[s].y, s1);
+                    }
+                }
+                v[j] = s0 + s1;
+            }
+            const int myrow = batch_sum<RESP>(v, lane);
+            if ((lane & (64 / RESP - 1)) == 0 && myrow < RES) lds_red[wave * R + myrow] = v[0];
+        }
         lds_barrier();
         if (stamp) pst[1] = wall_clock64();   // (behind the barrier: the workgroup's LAST wave has its sums)
         if (pub_col >= 0 && !(k == a.k0 && (int)blockIdx.x == a.mute_wg)) {   // (mute_wg: the test of the bounded waits)
@@ -333,12 +405,15 @@ __global__ __launch_bounds__(kStrThreads, 2) void k_cg_stream(ResidentArgs a)
         const double conj = ((dot[0] + dot[1]) + (dot[2] + dot[3])) + ((dot[4] + dot[5]) + (dot[6] + dot[7]));
         const double alpha = safeguarded_alpha(rsold, conj);             // cg.cc:107
         double rr = 0.0;
-        {
-            const d2 g = lds_ap[ap_own];
+        if (owner) {
+            const d2 g = lds_ap[ap_own], px = own[2 * own_n];
+            d2 xo = own[0], rx = own[own_n];
             xo.x = fma(alpha, px.x, xo.x);                               // cg.cc:110, the workgroup's own rows
             xo.y = fma(alpha, px.y, xo.y);
             rx.x = fma(-alpha, g.x, rx.x);
             rx.y = fma(-alpha, g.y, rx.y);
+            own[0] = xo;
+            own[own_n] = rx;
         }
 #pragma unroll
         for (int s = 0; s < S; ++s) {
@@ -351,7 +426,7 @@ __global__ __launch_bounds__(kStrThreads, 2) void k_cg_stream(ResidentArgs a)
         if (lane == 0) dot[W + wave] = rr;
         lds_barrier();
         const double *dr = dot + W;
-        const double rsnew = ((dr[0] + dr[1]) + (dr[2] + dr[3])) + ((dr[4] + dr[5]) + (dr[6] + dr[7]));   // cg.cc:116-117
+        const double rsnew = uniform(((dr[0] + dr[1]) + (dr[2] + dr[3])) + ((dr[4] + dr[5]) + (dr[6] + dr[7])));   // cg.cc:116-117
         if (sqrt(rsnew) < a.tol) {                                       // cg.cc:120-121: break before the p update
             rs_prev = rsnew;
             stop = 1;
@@ -363,16 +438,28 @@ __global__ __launch_bounds__(kStrThreads, 2) void k_cg_stream(ResidentArgs a)
             p[s].x = fma(beta, p[s].x, r[s].x);                          // cg.cc:127-129
             p[s].y = fma(beta, p[s].y, r[s].y);
         }
-        px.x = fma(beta, px.x, rx.x);
-        px.y = fma(beta, px.y, rx.y);
+        if (owner) {
+            const d2 rx = own[own_n];
+            d2 px = own[2 * own_n];
+            px.x = fma(beta, px.x, rx.x);
+            px.y = fma(beta, px.y, rx.y);
+            own[2 * own_n] = px;
+        }
         rs_prev = rsold;
         rsold = rsnew;                                                   // cg.cc:132
     }
 
     // ---- state back to memory: x by the workgroup that owns the rows, r / p / scalars by workgroup 0
     // (into the OUTPUT set: the state the launch started from stays intact, cgx_kernels.h)
-    if (sx >= 0) {
-        const int c = 2 * T * sx + 2 * tid;
+    // (the column indices are formed again from an opaque copy of tid: otherwise the compiler keeps the set-up's 64-bit indices alive
+    // across the whole loop for these few stores -- in scratch, where the registers are full)
+    int te = tid;
+    asm volatile("" : "+v"(te));
+    if (owner) {
+        const d2 *oe = own;
+        asm volatile("" : "+v"(oe));
+        const int c = 2 * ((int)(oe - lds_own) + (row0 >> 1));      // (= 2 T sx + 2 tid, from the one value that is alive anyway)
+        const d2 xo = own[0];
         if (ox0) a.out[c] = xo.x;
         if (ox1) a.out[c + 1] = xo.y;
     }
@@ -381,7 +468,7 @@ __global__ __launch_bounds__(kStrThreads, 2) void k_cg_stream(ResidentArgs a)
         Scalars *sc_out = reinterpret_cast<Scalars *>(a.out + state_off_sc(a.lda));
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            const int c = 2 * T * s + 2 * tid;
+            const int c = 2 * T * s + 2 * te;
             if (c < n) { r_out[c] = r[s].x; p_out[c] = p[s].x; }
             if (c + 1 < n) { r_out[c + 1] = r[s].y; p_out[c + 1] = p[s].y; }
         }
@@ -396,10 +483,10 @@ __global__ __launch_bounds__(kStrThreads, 2) void k_cg_stream(ResidentArgs a)
     // the ring's last loads (the rows of an iteration that never comes) are simply dropped with the wave
 }
 
-template <int S, int RB, int CH>
+template <int S, int RB, int CH, int RL, int RG>
 hipError_t with_stream_kernel(const ResidentPlan &pl, const ResidentArgs *a, hipStream_t s, int *per_cu)
 {
-    auto kern = k_cg_stream<S, RB, CH>;
+    auto kern = k_cg_stream<S, RB, CH, RL, RG>;
     if (!a) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pl.lds_bytes);
         if (e != hipSuccess) return e;
@@ -410,13 +497,17 @@ hipError_t with_stream_kernel(const ResidentPlan &pl, const ResidentArgs *a, hip
 }
 
 // ring depth: RB rows of S column steps, 12-20 slots of 16 bytes per thread in flight (96-160 KB per CU)
-constexpr int stream_rb(int S) { return S <= 2 ? 8 : S <= 5 ? 4 : S <= 10 ? 2 : 1; }
-constexpr int stream_ch(int S) { return S <= 4 ? S : S <= 9 ? 4 : 2; }
+constexpr int stream_rb(int S) { return S <= 2 ? 8 : S <= 4 ? 4 : S <= 10 ? 2 : 1; }
+constexpr int stream_ch(int S) { return S <= 4 ? S : 2; }
+// rows on the chip (n > 4096 only: below, the resident kernel runs): in the LDS what fits beside the parked Ap (8 KB S each of
+// 160 KB), in registers what the compiler places without a byte of scratch (tests/test_kernel_resources.py)
+constexpr int stream_rl(int S) { return S < 5 || S > 9 ? 0 : S <= 6 ? 2 : 1; }
+constexpr int stream_rg(int S) { return S == 5 ? 6 : S == 6 ? 4 : S == 7 ? 3 : S == 8 || S == 9 ? 1 : 0; }
 
 template <int S>
 hipError_t stream_dispatch_s(const ResidentPlan &pl, const ResidentArgs *a, hipStream_t s, int *per_cu)
 {
-    return with_stream_kernel<S, stream_rb(S), stream_ch(S)>(pl, a, s, per_cu);
+    return with_stream_kernel<S, stream_rb(S), stream_ch(S), stream_rl(S), stream_rg(S)>(pl, a, s, per_cu);
 }
 
 }  // namespace
@@ -453,10 +544,14 @@ bool plan_stream(int n, int cus, size_t lds_per_wg, ResidentPlan *out)
     pl.S = (n + 1023) / 1024;
     pl.RB = stream_rb(pl.S);
     pl.xslots = 1024 * pl.S;
-    pl.R = ((n + G - 1) / G + pl.RB - 1) / pl.RB * pl.RB;     // rows per workgroup, a whole number of batches
+    pl.RL = stream_rl(pl.S);
+    pl.RG = stream_rg(pl.S);
+    const int res = pl.RL + pl.RG, need = (n + G - 1) / G;
+    if (need <= res) return false;                            // (never with n > 4096: 17 rows per workgroup and more)
+    pl.R = res + (need - res + pl.RB - 1) / pl.RB * pl.RB;    // rows per workgroup: those on the chip + a whole number of batches
     pl.rows_per_wg = pl.R;
     pl.grid = (n + pl.R - 1) / pl.R;
-    pl.lds_bytes = ((size_t)kStrWaves * pl.R + 4 * kStrWaves + kStrWaves + 4 + (size_t)2 * pl.S * kStrThreads) * sizeof(double);
+    pl.lds_bytes = ((size_t)kStrWaves * pl.R + 4 * kStrWaves + kStrWaves + 4 + (size_t)2 * pl.S * kStrThreads * (1 + pl.RL) + (size_t)6 * (pl.R / 2 + 2)) * sizeof(double);
     if (pl.R >= kStrThreads || pl.lds_bytes > lds_per_wg) return false;
     *out = pl;
     return true;

@@ -1,5 +1,5 @@
 """The streaming persistent kernel (csrc/cgx_stream.hip: the loop code/MPI/cg.cc:95-137 as ONE persistent kernel that streams
-every row of A; 4096 < n <= 16384 on one GPU, the library's default up to n = 8192) against the oracle and against the
+every row of A; 4096 < n <= 16384 on one GPU, the library's default up to n = 9216) against the oracle and against the
 per-launch path.  All marked gpu.
 
 gemv_variant 50000 asks for this kernel whatever the size (1024 <= n <= 16384; an expired wait is then an error); 0 is the
@@ -90,10 +90,10 @@ def test_baseline_config_2_to_convergence(gpu_pkg, monkeypatch):
 
 
 def test_the_library_default(gpu_pkg, oracle, monkeypatch):
-    """gemv_variant 0: the streaming kernel from n = 4097 to n = 8192 (where it measures faster than K1 + K3), the per-launch path
+    """gemv_variant 0: the streaming kernel from n = 4097 to n = 9216 (where it measures faster than K1 + K3), the per-launch path
     above; CGX_STREAM_MAX moves that end; CGX_RESIDENT=0 and -1 keep the per-launch path."""
     monkeypatch.delenv("CGX_RESIDENT", raising=False)
-    for n, want in ((4097, 5), (6000, 5), (8192, 5), (8193, 1), (12000, 1)):
+    for n, want in ((4097, 5), (6000, 5), (8192, 5), (8193, 5), (9216, 5), (9217, 1), (12000, 1)):
         with lap(gpu_pkg, n, 0) as s:
             assert s.gemv_plan()["variant"] == want, n
     monkeypatch.setenv("CGX_STREAM_MAX", "12288")
@@ -221,7 +221,7 @@ def test_context_reuse_across_sizes_and_kernels(gpu_pkg, monkeypatch):
     forth: every solve gives the bits of a fresh context (exchange buffer laid out anew per geometry, epochs only grow, the two
     state blocks rebound per problem)."""
     monkeypatch.delenv("CGX_RESIDENT", raising=False)
-    sizes = (2048, 5000, 9000, 8192, 1024, 6144)
+    sizes = (2048, 5000, 9500, 8192, 1024, 6144)
     fresh = {}
     for n in sizes:
         with lap(gpu_pkg, n, 0, 40, 0.0) as s:
@@ -230,7 +230,7 @@ def test_context_reuse_across_sizes_and_kernels(gpu_pkg, monkeypatch):
             fresh[n] = (x, s.gemv_plan()["variant"])
     assert [fresh[n][1] for n in sizes] == [4, 5, 1, 5, 4, 5]
     with gpu_pkg.CGSolver(gemv_variant=0) as s:
-        for n in (5000, 2048, 8192, 9000, 5000, 1024, 6144, 8192, 2048):
+        for n in (5000, 2048, 8192, 9500, 5000, 1024, 6144, 8192, 2048):
             s.generate_lap2d_matrix(n)
             s.set_max_iter(40)
             s.tolerance(0.0)
@@ -342,3 +342,21 @@ def test_cgsolver_cli(gpu_pkg, oracle, tmp_path):
     _, ro = oracle.solve_lap2d(5000, None, 1e-10, 1)
     ks = {name: int(re.search(r"\[STEP (\d+)\]", text).group(1)) for name, text in outs.items()}
     assert abs(ks["stream"] - ro["iterations"]) <= 0.15 * ro["iterations"] + 1 and abs(ks["stream"] - ks["launches"]) <= 30
+
+
+def test_where_a_workgroup_begins_its_sweep_changes_no_bit():
+    """Every workgroup begins its sweep at a batch of its own (CGX_STREAM_STAGGER, default 1; 0 = all at their first rows): the rows
+    are independent, so x must not differ in a single bit.  The switch is read once per process: two child processes."""
+    code = ("import sys, hashlib, numpy as np; sys.path.insert(0, %r); import torch, __graft_entry__ as g; pkg = g.load_package()\n"
+            "for n in (4500, 5120, 7000, 8192, 10000):\n"
+            "    s = pkg.CGSolver(gemv_variant=50000); s.generate_lap2d_matrix(n); s.set_max_iter(60); s.tolerance(0.0)\n"
+            "    s.init_source_term(1.0 / n); x = np.zeros(n); s.solve(x); s.close()\n"
+            "    print(n, hashlib.sha256(x.tobytes()).hexdigest())\n" % ROOT)
+    out = []
+    for v in ("0", "1"):
+        env = dict(os.environ, CGX_STREAM_STAGGER=v)
+        env.pop("CGX_RESIDENT", None)
+        p = subprocess.run(["python3", "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out.append([l for l in p.stdout.splitlines() if l and l[0].isdigit()])
+    assert len(out[0]) == 5 and out[0] == out[1], out
