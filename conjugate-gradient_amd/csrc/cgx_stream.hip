@@ -12,7 +12,7 @@
 //           workgroup g owns the R consecutive rows g R ... g R + R - 1, R = ceil(n / 256) rounded up so that the streamed
 //           rows are a whole number of batches; its first RL rows are copied into the LDS and the next RG into registers once
 //           per launch (the thread keeps the pairs it multiplies), the other R - RL - RG are streamed every iteration:
-//           S = 5 (n <= 5120): 2 + 6 of 20 rows; S = 6: 2 + 4 of 24; S = 7: 1 + 3 of 28; S = 8 (n <= 8192): 1 + 1 of 32;
+//           S = 5 (n <= 5120): 2 + 6 of 20 rows; S = 6: 2 + 4 of 24; S = 7: 1 + 3 of 28; S = 8 (n <= 8192): 1 + 2 of 32;
 //           S = 9: 1 + 1 of 36; above: none (the LDS holds the parked Ap, 8 KB S, and nothing else of that size);
 //   state = r, p in registers, replicated in every workgroup: thread t owns the column pairs {1024 s + 2 t, + 1}, s < S =
 //           ceil(n / 1024) -- the same columns whose entries of A it streams, so the GEMV needs no vector traffic at all;
@@ -30,7 +30,9 @@
 //                                 one wave reduction (v_permlane swaps + DPP), per row 8 wave partials in LDS    cg.cc:100-102
 //     publish Ap_sub              R tagged doubles per workgroup (cgx_tagged.h)
 //     gather Ap                   every thread polls one watched word, then the tagged words of its 2 S columns in chunks of
-//                                 4 (agent-scope buffer loads: one 32-bit lane offset, parity and column step scalar)
+//                                 2 or 4 (agent-scope buffer loads: one 32-bit lane offset, parity and column step scalar; once
+//                                 the watched word is there the others are L2 hits: small chunks cost no time, large ones
+//                                 cost the registers of a row of A)
 //     p.Ap, alpha, x, r, r.r, break test, beta, p: as cgx_resident.hip, every workgroup over the whole vectors, same order:
 //                                 bit-identical everywhere                                                         cg.cc:105-132
 //
@@ -498,11 +500,11 @@ hipError_t with_stream_kernel(const ResidentPlan &pl, const ResidentArgs *a, hip
 
 // ring depth: RB rows of S column steps, 12-20 slots of 16 bytes per thread in flight (96-160 KB per CU)
 constexpr int stream_rb(int S) { return S <= 2 ? 8 : S <= 4 ? 4 : S <= 10 ? 2 : 1; }
-constexpr int stream_ch(int S) { return S <= 4 ? S : 2; }
+constexpr int stream_ch(int S) { return S <= 4 ? S : S == 8 ? 1 : 2; }
 // rows on the chip (n > 4096 only: below, the resident kernel runs): in the LDS what fits beside the parked Ap (8 KB S each of
 // 160 KB), in registers what the compiler places without a byte of scratch (tests/test_kernel_resources.py)
 constexpr int stream_rl(int S) { return S < 5 || S > 9 ? 0 : S <= 6 ? 2 : 1; }
-constexpr int stream_rg(int S) { return S == 5 ? 6 : S == 6 ? 4 : S == 7 ? 3 : S == 8 || S == 9 ? 1 : 0; }
+constexpr int stream_rg(int S) { return S == 5 ? 6 : S == 6 ? 4 : S == 7 ? 3 : S == 8 ? 2 : S == 9 ? 1 : 0; }
 
 template <int S>
 hipError_t stream_dispatch_s(const ResidentPlan &pl, const ResidentArgs *a, hipStream_t s, int *per_cu)

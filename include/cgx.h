@@ -78,9 +78,11 @@ typedef struct cgx_config {
                                  block size -- or, for a dense matrix of n <= 16384 on one GPU (CGX_COMM_SELF), a PERSISTENT kernel:
                                  the whole loop cg.cc:95-137 as ONE launch whose workgroups exchange Ap among themselves.
                                  n <= 4096: every row group of A stays on the chip, in a CU's LDS (n <= 2048) or in its LDS and
-                                 registers with a streamed rest (csrc/cgx_resident.hip; 3-9 us per iteration instead of 7-26);
-                                 4096 < n <= 16384: every row is streamed, the vectors stay in registers (csrc/cgx_stream.hip;
-                                 DESIGN.md section 4c).  What the default choice rests on, and what happens when it fails:
+                                 registers with a streamed rest (csrc/cgx_resident.hip; 2.3-6 us per iteration instead of 7-26);
+                                 4096 < n <= 16384: the rows are streamed (all but the few that fit beside them), the vectors
+                                 stay in registers (csrc/cgx_stream.hip; the default up to n = 9216, where it measures faster:
+                                 20 / 74 / 97 us per iteration at n = 5120 / 8192 / 9216 instead of 36 / 80 / 104; CGX_STREAM_MAX
+                                 moves that end).  What the default choice rests on, and what happens when it fails:
                                  all workgroups of such a kernel must be resident at once (checked against the runtime's
                                  occupancy when the problem is set; another tenant of the GPU can still break it), and the
                                  exchange rests on an aligned 8-byte half of a 16-byte write-through store being seen untorn
