@@ -22,10 +22,10 @@ using namespace cgxi;
 namespace cgxi {
 
 // Largest n the DEFAULT choice hands to the streaming persistent kernel: measured against the per-launch path it wins up to
-// N = 9216 (20.3 / 34.8 / 54.4 / 76.2 / 96.9 us per iteration at N = 5120 / 6144 / 7168 / 8192 / 9216 against 36.3 / 48.3 / 66.0 /
-// 80.3 / 105.8) and ties above (119.6 against 119.4-120.4 at N = 10000, where no row of A fits on the chip beside the vectors:
-// DESIGN.md section 4c)
-constexpr int kStreamDefaultMax = 9216;
+// N = 10000 (20.5 / 34.9 / 54.7 / 73.9 / 96.9 / 105.6 / 117.7 us per iteration at N = 5120 / 6144 / 7168 / 8192 / 9216 / 9500 / 10000
+// against 35.7 / 47.7 / 65.2 / 79.8 / 104.1 / 110.8 / 118.8) and loses above (124.9 against 123.0 at N = 10240; from there no row of A
+// fits on the chip beside the vectors: DESIGN.md section 4c)
+constexpr int kStreamDefaultMax = 10000;
 
 thread_local std::string g_create_error;
 

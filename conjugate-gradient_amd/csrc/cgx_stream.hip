@@ -13,7 +13,8 @@
 //           rows are a whole number of batches; its first RL rows are copied into the LDS and the next RG into registers once
 //           per launch (the thread keeps the pairs it multiplies), the other R - RL - RG are streamed every iteration:
 //           S = 5 (n <= 5120): 2 + 6 of 20 rows; S = 6: 2 + 4 of 24; S = 7: 1 + 3 of 28; S = 8 (n <= 8192): 1 + 2 of 32;
-//           S = 9: 1 + 1 of 36; above: none (the LDS holds the parked Ap, 8 KB S, and nothing else of that size);
+//           S = 9: 1 + 1 of 36; S = 10 (n <= 10240): 0 + 1 of 40, with a ring of one row; above: none (the LDS holds the parked
+//           Ap, 8 KB S, and nothing else of that size; a row costs 4 S registers);
 //   state = r, p in registers, replicated in every workgroup: thread t owns the column pairs {1024 s + 2 t, + 1}, s < S =
 //           ceil(n / 1024) -- the same columns whose entries of A it streams, so the GEMV needs no vector traffic at all;
 //   A     = streamed through a RING of RB x S 16-byte registers per thread (RB rows of the thread's columns): a slot is
@@ -499,12 +500,12 @@ hipError_t with_stream_kernel(const ResidentPlan &pl, const ResidentArgs *a, hip
 }
 
 // ring depth: RB rows of S column steps, 12-20 slots of 16 bytes per thread in flight (96-160 KB per CU)
-constexpr int stream_rb(int S) { return S <= 2 ? 8 : S <= 4 ? 4 : S <= 10 ? 2 : 1; }
-constexpr int stream_ch(int S) { return S <= 4 ? S : S == 8 ? 1 : 2; }
+constexpr int stream_rb(int S) { return S <= 2 ? 8 : S <= 4 ? 4 : S <= 9 ? 2 : 1; }
+constexpr int stream_ch(int S) { return S <= 4 ? S : S == 8 || S == 10 ? 1 : 2; }
 // rows on the chip (n > 4096 only: below, the resident kernel runs): in the LDS what fits beside the parked Ap (8 KB S each of
 // 160 KB), in registers what the compiler places without a byte of scratch (tests/test_kernel_resources.py)
 constexpr int stream_rl(int S) { return S < 5 || S > 9 ? 0 : S <= 6 ? 2 : 1; }
-constexpr int stream_rg(int S) { return S == 5 ? 6 : S == 6 ? 4 : S == 7 ? 3 : S == 8 ? 2 : S == 9 ? 1 : 0; }
+constexpr int stream_rg(int S) { return S == 5 ? 6 : S == 6 ? 4 : S == 7 ? 3 : S == 8 ? 2 : S == 9 || S == 10 ? 1 : 0; }
 
 template <int S>
 hipError_t stream_dispatch_s(const ResidentPlan &pl, const ResidentArgs *a, hipStream_t s, int *per_cu)
