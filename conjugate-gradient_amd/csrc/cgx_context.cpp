@@ -22,8 +22,8 @@ using namespace cgxi;
 namespace cgxi {
 
 // Largest n the DEFAULT choice hands to the streaming persistent kernel: measured against the per-launch path it wins up to
-// N = 10000 (20.5 / 34.9 / 54.7 / 73.9 / 96.9 / 105.6 / 117.7 us per iteration at N = 5120 / 6144 / 7168 / 8192 / 9216 / 9500 / 10000
-// against 35.7 / 47.7 / 65.2 / 79.8 / 104.1 / 110.8 / 118.8) and loses above (124.9 against 123.0 at N = 10240; from there no row of A
+// N = 10000 (18.8 / 32.3 / 52.5 / 72.1 / 94.2 / 105.9 / 117.5 us per iteration at N = 5120 / 6144 / 7168 / 8192 / 9216 / 9500 / 10000
+// against 35.6 / 47.7 / 65.1 / 79.5 / 104.1 / 111.1 / 119.0) and loses above (124.9 against 123.0 at N = 10240; from there no row of A
 // fits on the chip beside the vectors: DESIGN.md section 4c)
 constexpr int kStreamDefaultMax = 10000;
 

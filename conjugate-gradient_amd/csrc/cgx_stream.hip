@@ -12,8 +12,8 @@
 //           workgroup g owns the R consecutive rows g R ... g R + R - 1, R = ceil(n / 256) rounded up so that the streamed
 //           rows are a whole number of batches; its first RL rows are copied into the LDS and the next RG into registers once
 //           per launch (the thread keeps the pairs it multiplies), the other R - RL - RG are streamed every iteration:
-//           S = 5 (n <= 5120): 2 + 6 of 20 rows; S = 6: 2 + 4 of 24; S = 7: 1 + 3 of 28; S = 8 (n <= 8192): 1 + 2 of 32;
-//           S = 9: 1 + 1 of 36; S = 10 (n <= 10240): 0 + 1 of 40, with a ring of one row; above: none (the LDS holds the parked
+//           S = 5 (n <= 5120): 2 + 7 of 20 rows; S = 6: 2 + 5 of 24; S = 7: 1 + 4 of 28; S = 8 (n <= 8192): 1 + 3 of 32;
+//           S = 9: 1 + 2 of 36; S = 10 (n <= 10240): 0 + 1 of 40; above: none (the LDS holds the parked
 //           Ap, 8 KB S, and nothing else of that size; a row costs 4 S registers);
 //   state = r, p in registers, replicated in every workgroup: thread t owns the column pairs {1024 s + 2 t, + 1}, s < S =
 //           ceil(n / 1024) -- the same columns whose entries of A it streams, so the GEMV needs no vector traffic at all;
@@ -23,7 +23,7 @@
 //           for all of them; rows and columns outside the block read as 0 by the range check), issued through the compiler's
 //           builtins, so every wait on streamed data is the compiler's own vmcnt bookkeeping (no hand-written waits: ADVICE r4).  The rows do not depend on p, so the ring simply
 //           wraps around: while the workgroups exchange Ap and update r and p, the first RB rows of the NEXT iteration are
-//           already in flight (128 KB per CU at N = 8192) and the memory pipe does not run dry across the iteration boundary;
+//           already in flight (64 KB per CU at N = 8192) and the memory pipe does not run dry across the iteration boundary;
 //           every workgroup begins its sweep at a batch of its own (phi, below: 256 streams in step meet in the same memory
 //           channels for some row pitches otherwise);
 //   one iteration (cg.cc:96-137) =
@@ -73,7 +73,7 @@ __device__ __forceinline__ bool tag_ok(const u4 &w, unsigned tag) { return ((w.y
 
 // v + v(lane ^ 16) and so on down to groups of 1: the sum over each half wave, every lane of the half gets it; the 16-lane
 // level by v_permlane16_swap (VALU) instead of a ds_bpermute round trip (same pairing as group_sum<32>, same bits)
-__device__ __forceinline__ double half_wave_sum_swap(double v)
+__device__ __forceinline__ __attribute__((unused)) double half_wave_sum_swap(double v)
 {
     const auto lo = __builtin_amdgcn_permlane16_swap(__double2loint(v), __double2loint(v), false, false);
     const auto hi = __builtin_amdgcn_permlane16_swap(__double2hiint(v), __double2hiint(v), false, false);
@@ -104,8 +104,8 @@ __global__ __launch_bounds__(kStrThreads, 2) void k_cg_stream(ResidentArgs a)
 {
     constexpr int T = kStrThreads, W = kStrWaves;
     constexpr int RES = RL + RG;                                       // rows on the chip
-    constexpr int RESP = RES <= 1 ? 1 : RES <= 2 ? 2 : RES <= 4 ? 4 : 8;   // ... their sums are reduced together: a power of two
-    static_assert(RES <= 8, "at most 8 rows on the chip");
+    constexpr int RESP = RES <= 1 ? 1 : RES <= 2 ? 2 : RES <= 4 ? 4 : RES <= 8 ? 8 : 16;   // ... their sums are reduced together: a power of two
+    static_assert(RES <= 16, "at most 16 rows on the chip");
     extern __shared__ double lds_all[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = a.n, R = a.rows_per_wg, nb = (R - RES) / RB;
@@ -499,13 +499,15 @@ hipError_t with_stream_kernel(const ResidentPlan &pl, const ResidentArgs *a, hip
     return hipGetLastError();
 }
 
-// ring depth: RB rows of S column steps, 12-20 slots of 16 bytes per thread in flight (96-160 KB per CU)
-constexpr int stream_rb(int S) { return S <= 2 ? 8 : S <= 4 ? 4 : S <= 9 ? 2 : 1; }
+// ring depth: RB rows of S column steps.  From S = 5 ONE row (5-16 slots of 16 bytes per thread, 40-128 KB per CU in flight): measured,
+// a second row in flight gains nothing, and its 4 S registers hold a row of A instead (N = 8192: 73.7 -> 71.6 us per iteration,
+// 5120: 20.3 -> 18.8, 9216: 96.5 -> 93.7)
+constexpr int stream_rb(int S) { return S <= 2 ? 8 : S <= 4 ? 4 : 1; }
 constexpr int stream_ch(int S) { return S <= 4 ? S : S == 8 || S == 10 ? 1 : 2; }
 // rows on the chip (n > 4096 only: below, the resident kernel runs): in the LDS what fits beside the parked Ap (8 KB S each of
 // 160 KB), in registers what the compiler places without a byte of scratch (tests/test_kernel_resources.py)
 constexpr int stream_rl(int S) { return S < 5 || S > 9 ? 0 : S <= 6 ? 2 : 1; }
-constexpr int stream_rg(int S) { return S == 5 ? 6 : S == 6 ? 4 : S == 7 ? 3 : S == 8 ? 2 : S == 9 || S == 10 ? 1 : 0; }
+constexpr int stream_rg(int S) { return S == 5 ? 7 : S == 6 ? 5 : S == 7 ? 4 : S == 8 ? 3 : S == 9 ? 2 : S == 10 ? 1 : 0; }
 
 template <int S>
 hipError_t stream_dispatch_s(const ResidentPlan &pl, const ResidentArgs *a, hipStream_t s, int *per_cu)
