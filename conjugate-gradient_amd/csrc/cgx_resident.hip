@@ -60,15 +60,16 @@ constexpr int kResThreads = 256;
 // it: R = 16 rows per workgroup, RL rows in LDS, RG rows in REGISTERS (thread t holds its own 2 S columns of each: 4 S registers
 // per row, loaded once per launch), and the remaining RS rows streamed from memory every iteration (16-byte loads, default cache policy,
 // two rows per batch, the first batch of an iteration issued right behind the gather of the previous one).
-// S = 5: 7 + 9 + 0 (all resident, n <= 2560); S = 6: 6 + 10 + 0 (all resident, n <= 3072); S = 7: 5 + 9 + 2;
+// S = 5: 7 + 9 + 0 (all resident, n <= 2560); S = 6: 6 + 10 + 0 (all resident, n <= 3072); S = 7: 5 + 10 + 1;
 // S = 8: 4 + 8 + 4 (n = 4096: 32 of 128 MiB re-read per iteration).
 // ------------------------------------------------------------------------------------------------------------------------
 constexpr int kHybR = 16;
 constexpr int hyb_rl(int S) { return (150 * 1024) / (S * 512 * 8) < kHybR ? (150 * 1024) / (S * 512 * 8) : kHybR; }
 // rows in registers: what the 512 registers of a thread hold beside r, p, the row sums, a batch of streamed rows and the
 // gather's words without a byte of scratch (hipcc 7.2: 364 / 446 / 487 / 511 registers at S = 5 / 6 / 7 / 8)
-constexpr int hyb_rg(int S) { return S == 5 ? 9 : S == 6 ? 10 : S == 7 ? 9 : 8; }
-#define HYB_SB 2
+constexpr int hyb_rg(int S) { return S == 5 ? 9 : S == 6 ? 10 : S == 7 ? 10 : 8; }
+// streamed rows in flight at a time: two at S = 8 (4 streamed rows), one at S = 7 (1 streamed row: the second one's registers hold a row)
+constexpr int hyb_sb(int S) { return S == 8 ? 2 : 1; }
 
 // R = rows per workgroup, a power of two (the row sums are reduced together, wave_sum_rows; the last workgroup may own fewer);
 // S = column steps of 512; RL of the rows in LDS, RG in registers, the remaining R - RL - RG streamed every iteration.
@@ -77,7 +78,7 @@ template <int R, int S, int RL, int RG>
 __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
 {
     static_assert(RL >= 1 && RG >= 0 && RL + RG <= R, "rows in LDS + rows in registers <= rows per workgroup");
-    constexpr int RS = R - RL - RG, SB = HYB_SB;
+    constexpr int RS = R - RL - RG, SB = hyb_sb(S);
     extern __shared__ double lds_all[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = a.n;
@@ -182,6 +183,8 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
         rsold = block_sum<4>(v, lds_sum);
         rs_prev = rsold;
     }
+    rsold = uniform(rsold);     // (the same bits in every lane: kept in scalar registers across the iteration)
+    rs_prev = uniform(rs_prev);
     __syncthreads();   // the LDS rows are in place
 
     // The first batch of streamed rows of an iteration is issued as early as its buffer is free: the rows do not depend on p,
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
         rr = wave_sum_swap(rr);
         if (lane == 0) red[4 * R + 4 + wave] = rr;
         __syncthreads();
-        const double rsnew = (red[4 * R + 4] + red[4 * R + 5]) + (red[4 * R + 6] + red[4 * R + 7]);   // cg.cc:116-117
+        const double rsnew = uniform((red[4 * R + 4] + red[4 * R + 5]) + (red[4 * R + 6] + red[4 * R + 7]));   // cg.cc:116-117
         if (prof) {
             tp[5] = clock64();
             for (int i = 0; i < 5; ++i) a.prof[i] += tp[i + 1] - tp[i];
@@ -405,8 +408,12 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
     // ---- state back to memory: x by the workgroup that owns the rows, r / p / scalars by workgroup 0
     // (into the OUTPUT set: the state the launch started from stays intact, so that a launch whose waits expired can be redone
     // on the per-launch path, resident_steps in cgx_solve.cpp)
+    // (the column indices are formed again from an opaque copy of tid: otherwise the compiler keeps the set-up's 64-bit indices alive
+    // across the whole loop for these few stores)
+    int te = tid;
+    asm volatile("" : "+v"(te));
     if (sx >= 0) {
-        const int c = 512 * sx + 2 * tid;
+        const int c = 512 * sx + 2 * te;
         if (ox0) a.out[c] = xo.x;
         if (ox1) a.out[c + 1] = xo.y;
     }
@@ -415,7 +422,7 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
         Scalars *sc_out = reinterpret_cast<Scalars *>(a.out + state_off_sc(a.lda));
 #pragma unroll
         for (int s = 0; s < S; ++s) {
-            const int c = 512 * s + 2 * tid;
+            const int c = 512 * s + 2 * te;
             if ((okmask >> (2 * s)) & 1u) { r_out[c] = r[s].x; p_out[c] = p[s].x; }
             if ((okmask >> (2 * s + 1)) & 1u) { r_out[c + 1] = r[s].y; p_out[c + 1] = p[s].y; }
         }

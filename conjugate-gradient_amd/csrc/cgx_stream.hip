@@ -62,12 +62,6 @@ constexpr int kAuxSc1 = 16;                      // sc1: agent scope (loads past
 // (a poll is an sc1 load as well; what makes the compiler re-issue it every time round a loop is the `asm volatile("" ::: "memory")`
 // in front of it -- the intrinsic's own volatile bit would turn it into a system-scope sc0 sc1 load)
 
-// a value every lane holds alike, moved into scalar registers (two of them instead of two vector registers per lane)
-__device__ __forceinline__ double uniform(double v)
-{
-    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
-}
-
 __device__ __forceinline__ d2 as_d2(u4 w) { return __builtin_bit_cast(d2, w); }
 __device__ __forceinline__ bool tag_ok(const u4 &w, unsigned tag) { return ((w.y ^ tag) | (w.w ^ tag)) == 0; }
 

@@ -48,6 +48,12 @@ __device__ __forceinline__ void tagged_wait(u4 (&w)[2 * S])
     }
 }
 
+// a value every lane holds alike, moved into scalar registers (two of them instead of two vector registers per lane)
+__device__ __forceinline__ double uniform(double v)
+{
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
 // wait for the N 16-byte loads of a batch of streamed rows (the registers are operands, as in tagged_wait)
 template <int N>
 __device__ __forceinline__ void stream_wait(d2 *v)
