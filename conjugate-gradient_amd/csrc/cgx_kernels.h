@@ -257,7 +257,9 @@ struct ResidentPlan {
     int hybrid;        // 1 = 2048 < n <= 4096: R = 16 rows per workgroup, of which RL in LDS, RG in registers and
     int RL, RG;        //     R - RL - RG streamed from memory every iteration; 0: all R rows in LDS (RL = R, RG = 0)
     int stream;        // 1 = cgx_stream.hip (4096 < n <= 16384): workgroups of 512 threads, S = column steps of 1024, every row
-    int RB;            //     streamed through a ring of RB rows; R = rows per workgroup (a multiple of RB), nothing kept on chip
+    int RB;            //     streamed through a ring of RB rows; of the R rows per workgroup the first RL stay in LDS and the next RG in
+                       //     registers, the other R - RL - RG (a multiple of RB) are streamed every iteration
+    int l2_rows;       //     ... the first l2_rows of them with the default cache policy (they stay in the XCD's L2), the others nt
 };
 // One block of solver state (x | r + the update kernel's r.r partials | p | Scalars), offsets in doubles from its base.  On one
 // GPU the shard keeps TWO such blocks (cgx_context.cpp): the persistent kernels read one and write the other.
@@ -296,6 +298,7 @@ struct ResidentArgs {
     double tol;
     long long timeout_ticks;    // bound of every wait, 100 MHz wall-clock ticks
     int *err;          // device word raised when a wait expired
+    int l2_rows;       // streaming kernel: the first l2_rows streamed rows of every workgroup are read with the default cache policy (the others nt)
     int stagger;       // streaming kernel: every workgroup begins its sweep at a batch of its own (0 = all at their first rows)
     int mute_wg;       // test only (cgx_probe_resident_test): this workgroup leaves out the publish of the launch's first iteration; -1 = none
     ResidentTail *tail;   // PINNED HOST memory: what the launch reports back (written by the kernel itself: no copy command)

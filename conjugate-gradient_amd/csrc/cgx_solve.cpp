@@ -370,6 +370,8 @@ cgx_status resident_steps(cgx_ctx *ctx, int nsteps, int *redo)
         {
             static const int stagger = [] { const char *e = getenv("CGX_STREAM_STAGGER"); return e ? atoi(e) : 1; }();
             a.stagger = stagger;
+            static const int l2_rows = [] { const char *e = getenv("CGX_STREAM_L2_ROWS"); return e ? atoi(e) : -1; }();
+            a.l2_rows = l2_rows >= 0 ? l2_rows : ctx->rplan.l2_rows;
         }
         a.mute_wg = ctx->res_mute_wg;
         ctx->res_mute_wg = -1;

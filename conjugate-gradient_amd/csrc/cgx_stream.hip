@@ -140,6 +140,10 @@ __global__ __launch_bounds__(kStrThreads, 2) void k_cg_stream(ResidentArgs a)
     auto a_issue = [&](int i, int s) {
         return as_d2(__builtin_amdgcn_raw_buffer_load_b128(rs_a, s == S - 1 ? voff_last : voff, (int)((unsigned)min(row0 + i, n - 1) * pitch_b + 16u * T * s), kAuxNt));
     };
+    // the same with the default cache policy: for the workgroup's first a.l2_rows streamed rows, which are meant to stay in the XCD's L2
+    auto a_issue_l2 = [&](int i, int s) {
+        return as_d2(__builtin_amdgcn_raw_buffer_load_b128(rs_a, s == S - 1 ? voff_last : voff, (int)((unsigned)min(row0 + i, n - 1) * pitch_b + 16u * T * s), 0));
+    };
     // the exchange buffer: [2 parities][1024 S tagged doubles of 16 bytes]
     const rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(a.xbuf, 0, 2 * a.xslots * 16, 0x00020000);
 
@@ -165,6 +169,7 @@ __global__ __launch_bounds__(kStrThreads, 2) void k_cg_stream(ResidentArgs a)
 #pragma unroll
         for (int s = 0; s < S; ++s) ring[j][s] = d2{0.0, 0.0};
     int b_first = -1, pcur = 0;
+    const int l2_batches = a.l2_rows / RB;          // the first streamed batches are read with the default cache policy
     // where this workgroup begins its sweep: a batch of its own (a hash of the workgroup's number).  The workgroups sweep in step, and
     // with all of them at the same place in their rows the 256 streams lie multiples of R x pitch apart -- for some pitches
     // in the same memory channels (N = 8192, pitch + 512 B: 102 instead of 75 us; N = 8704, + 256 B: 109 instead of 87).  The
@@ -271,18 +276,34 @@ __global__ __launch_bounds__(kStrThreads, 2) void k_cg_stream(ResidentArgs a)
             if (pn >= nb) pn -= nb;
             const int nxt = RES + pn * RB;
             double v[RB];
+            if (pn < l2_batches) {                       // (workgroup-uniform: the same number of loads on either side)
 #pragma unroll
-            for (int j = 0; j < RB; ++j) {
-                double s0 = 0.0, s1 = 0.0;
+                for (int j = 0; j < RB; ++j) {
+                    double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const d2 av = ring[j][s];
-                    s0 = fma(av.x, p[s].x, s0);
-                    s1 = fma(av.y, p[s].y, s1);
-                    ring[j][s] = a_issue(nxt + j, s);
-                    __builtin_amdgcn_sched_barrier(0);
+                    for (int s = 0; s < S; ++s) {
+                        const d2 av = ring[j][s];
+                        s0 = fma(av.x, p[s].x, s0);
+                        s1 = fma(av.y, p[s].y, s1);
+                        ring[j][s] = a_issue_l2(nxt + j, s);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    v[j] = s0 + s1;
                 }
-                v[j] = s0 + s1;
+            } else {
+#pragma unroll
+                for (int j = 0; j < RB; ++j) {
+                    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const d2 av = ring[j][s];
+                        s0 = fma(av.x, p[s].x, s0);
+                        s1 = fma(av.y, p[s].y, s1);
+                        ring[j][s] = a_issue(nxt + j, s);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    v[j] = s0 + s1;
+                }
             }
             const int myrow = batch_sum<RB>(v, lane);
             if (b >= 0 && (lane & (64 / RB - 1)) == 0) lds_red[wave * R + RES + pcur * RB + myrow] = v[0];
@@ -500,6 +521,11 @@ constexpr int stream_rb(int S) { return S <= 2 ? 8 : S <= 4 ? 4 : 1; }
 constexpr int stream_ch(int S) { return S <= 4 ? S : S == 8 || S == 10 ? 1 : 2; }
 // rows on the chip (n > 4096 only: below, the resident kernel runs): in the LDS what fits beside the parked Ap (8 KB S each of
 // 160 KB), in registers what the compiler places without a byte of scratch (tests/test_kernel_resources.py)
+// streamed rows read with the default cache policy instead of nt: a workgroup always runs on the same XCD, and what 32 workgroups
+// read of two 40-KB rows each (2.6 MB) is still in that XCD's 4-MB L2 an iteration later.  Measured (CGX_STREAM_L2_ROWS = 0 / 1 /
+// 2 / 3 / 4): N = 4608: 15.4 / 14.3 / 14.0 / 14.6 / 15.7 us per iteration, 5120: 18.7 / 17.8 / 17.8 / 18.8 / 19.2, 6144: 32.3 / 31.6 /
+// 32.8 / 33.2 / 33.0, 7168: 52.9 / 50.5 / 51.3 / 51.4 / 50.8, from 8192 no difference (a row of 64 KB x 32 is half the L2)
+constexpr int stream_l2_rows(int S) { return S == 5 ? 2 : S == 6 || S == 7 ? 1 : 0; }
 constexpr int stream_rl(int S) { return S < 5 || S > 9 ? 0 : S <= 6 ? 2 : 1; }
 constexpr int stream_rg(int S) { return S == 5 ? 7 : S == 6 ? 5 : S == 7 ? 4 : S == 8 ? 3 : S == 9 ? 2 : S == 10 ? 1 : 0; }
 
@@ -545,6 +571,7 @@ bool plan_stream(int n, int cus, size_t lds_per_wg, ResidentPlan *out)
     pl.xslots = 1024 * pl.S;
     pl.RL = stream_rl(pl.S);
     pl.RG = stream_rg(pl.S);
+    pl.l2_rows = stream_l2_rows(pl.S);
     const int res = pl.RL + pl.RG, need = (n + G - 1) / G;
     if (need <= res) return false;                            // (never with n > 4096: 17 rows per workgroup and more)
     pl.R = res + (need - res + pl.RB - 1) / pl.RB * pl.RB;    // rows per workgroup: those on the chip + a whole number of batches
