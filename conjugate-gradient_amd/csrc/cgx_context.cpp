@@ -22,10 +22,11 @@ using namespace cgxi;
 namespace cgxi {
 
 // Largest n the DEFAULT choice hands to the streaming persistent kernel: measured against the per-launch path it wins up to
-// N = 10000 (18.8 / 32.3 / 52.5 / 72.1 / 94.2 / 105.9 / 117.5 us per iteration at N = 5120 / 6144 / 7168 / 8192 / 9216 / 9500 / 10000
-// against 35.6 / 47.7 / 65.1 / 79.5 / 104.1 / 111.1 / 119.0) and loses above (124.9 against 123.0 at N = 10240; from there no row of A
-// fits on the chip beside the vectors: DESIGN.md section 4c)
-constexpr int kStreamDefaultMax = 10000;
+// N = 9216 by 8 % and more (17.9 / 31.8 / 50.6 / 70.5 / 95.3 us per iteration at N = 5120 / 6144 / 7168 / 8192 / 9216 against 36.1 / 47.7 /
+// 65.2 / 79.7 / 103.9, the slower of two boxes).  From N = 9500 to 11264 the two are within 3 % of each other, and which one is ahead
+// changes from box to box (N = 10000: 116.7 against 118.9 on one, 120.5 against 118.8 on the other -- the per-launch figure is the
+// stable one: a persistent kernel ends with its slowest workgroup); above, the streaming kernel loses
+constexpr int kStreamDefaultMax = 9216;
 
 thread_local std::string g_create_error;
 

@@ -13,7 +13,7 @@
 //           rows are a whole number of batches; its first RL rows are copied into the LDS and the next RG into registers once
 //           per launch (the thread keeps the pairs it multiplies), the other R - RL - RG are streamed every iteration:
 //           S = 5 (n <= 5120): 2 + 7 of 20 rows; S = 6: 2 + 5 of 24; S = 7: 1 + 4 of 28; S = 8 (n <= 8192): 1 + 3 of 32;
-//           S = 9: 1 + 2 of 36; S = 10 (n <= 10240): 0 + 1 of 40; above: none (the LDS holds the parked
+//           S = 9: 1 + 2 of 36; S = 10 (n <= 10240): 0 + 1 of 40; S = 11: 0 + 1 of 44; above: none (the LDS holds the parked
 //           Ap, 8 KB S, and nothing else of that size; a row costs 4 S registers);
 //   state = r, p in registers, replicated in every workgroup: thread t owns the column pairs {1024 s + 2 t, + 1}, s < S =
 //           ceil(n / 1024) -- the same columns whose entries of A it streams, so the GEMV needs no vector traffic at all;
@@ -527,7 +527,7 @@ constexpr int stream_ch(int S) { return S <= 4 ? S : S == 8 || S == 10 ? 1 : 2; 
 // 32.8 / 33.2 / 33.0, 7168: 52.9 / 50.5 / 51.3 / 51.4 / 50.8, from 8192 no difference (a row of 64 KB x 32 is half the L2)
 constexpr int stream_l2_rows(int S) { return S == 5 ? 2 : S == 6 || S == 7 ? 1 : 0; }
 constexpr int stream_rl(int S) { return S < 5 || S > 9 ? 0 : S <= 6 ? 2 : 1; }
-constexpr int stream_rg(int S) { return S == 5 ? 7 : S == 6 ? 5 : S == 7 ? 4 : S == 8 ? 3 : S == 9 ? 2 : S == 10 ? 1 : 0; }
+constexpr int stream_rg(int S) { return S == 5 ? 7 : S == 6 ? 5 : S == 7 ? 4 : S == 8 ? 3 : S == 9 ? 2 : S == 10 || S == 11 ? 1 : 0; }
 
 template <int S>
 hipError_t stream_dispatch_s(const ResidentPlan &pl, const ResidentArgs *a, hipStream_t s, int *per_cu)

@@ -6,8 +6,8 @@ and waits for them a whole loop trip later: a register-allocator spill or copy o
 that window would read a register whose load has not landed, and nothing validates A's streamed rows.  The kernels sit at
 487-511 of 512 registers, so a toolchain bump could introduce exactly that: this test fails the build if ANY instantiation of
 k_cg_resident spills a vector register or touches scratch.  csrc/cgx_stream.hip leaves every wait to the compiler (buffer-load
-builtins), so a spill there costs time, not correctness: the instantiations the library's default uses (n <= 10000: S <= 10)
-must be spill-free -- they sit at 227-256 of 256 registers because every register that is free holds a piece
+builtins), so a spill there costs time, not correctness: the instantiations that hold rows of A on the chip (n <= 11264: S <= 11;
+the library's default uses them up to S = 9) must be spill-free -- they sit at 227-256 of 256 registers because every register that is free holds a piece
 of a row of A; the others may spill outside the sweep (documented in DESIGN.md) but must still build."""
 import os
 import re
@@ -54,5 +54,5 @@ def test_stream_kernels_of_the_default_range_never_spill():
     for r in rows:
         s = int(re.search(r"k_cg_stream<(\d+),", r["name"]).group(1))
         assert int(r["VGPRs"]) <= 256, r                        # two waves per SIMD: one workgroup of 512 threads per CU
-        if s <= 10:
+        if s <= 11:
             assert int(r["VGPRs Spill"]) == 0 and int(r["ScratchSize [bytes/lane]"]) == 0, r
