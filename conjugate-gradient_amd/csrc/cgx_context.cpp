@@ -623,7 +623,7 @@ cgx_status cgx_get_gemv_plan(const cgx_ctx *ctx, int local_shard, int out[CGX_GE
     if (!ctx || !out || local_shard < 0 || local_shard >= (int)ctx->shards.size()) return CGX_ERR_BAD_ARG;
     const cgx::GemvPlan &pl = ctx->shards[(size_t)local_shard].plan;
     if (ctx->resident && ctx->rplan.stream) {   // variant 5: the loop runs as one persistent kernel that streams every row (U = column steps of 1024)
-        const int r[CGX_GEMV_PLAN_INTS] = {5, ctx->rplan.R, ctx->rplan.S, 8, ctx->rplan.RB, 1, ctx->rplan.grid, pl.ncols};   // light = rows per batch of the ring
+        const int r[CGX_GEMV_PLAN_INTS] = {5, ctx->rplan.R, ctx->rplan.S, 8, ctx->rplan.RB, ctx->rplan.RL + ctx->rplan.RG, ctx->rplan.grid, pl.ncols};   // light = rows per batch of the ring, split = rows of a workgroup kept on the chip
         memcpy(out, r, sizeof r);
         return CGX_OK;
     }

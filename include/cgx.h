@@ -173,7 +173,7 @@ cgx_status  cgx_get_comm_info(cgx_ctx *ctx, int *comm_mode, int *ranks_wired, in
  * runs in the resident persistent kernel, 5 = in the streaming persistent kernel), R rows per workgroup (variant 2: per
  * wave), U steps in flight (variant 4 / 5: column steps of 512 / 1024), waves per workgroup, light (1 = the one-round form;
  * variant 4: rows of a workgroup held in registers, 0 up to n = 2048; variant 5: rows per batch of the ring), split (column
- * pieces per row group, tied to the XCDs), grid (workgroups of one fused launch; variant 4 / 5: of the persistent kernel, all
+ * pieces per row group, tied to the XCDs; variant 5: rows of a workgroup that stay in LDS and registers instead of being streamed), grid (workgroups of one fused launch; variant 4 / 5: of the persistent kernel, all
  * resident at once), ncols (columns swept)}.  After a persistent launch has been redone on the per-launch path (gemv_variant
  * above) this reports the per-launch shape. */
 #define CGX_GEMV_PLAN_INTS 8

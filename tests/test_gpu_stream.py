@@ -96,9 +96,14 @@ def test_the_library_default(gpu_pkg, oracle, monkeypatch):
     for n, want in ((4097, 5), (6000, 5), (8192, 5), (8193, 5), (9216, 5), (9217, 1), (10000, 1), (12000, 1)):
         with lap(gpu_pkg, n, 0) as s:
             assert s.gemv_plan()["variant"] == want, n
+    # the shape the plan reports: rows per workgroup, column steps of 1024, rows kept on the chip ("split"), one-row ring ("light")
+    for n, rows, steps, chip in ((5120, 20, 5, 9), (8192, 32, 8, 4), (9216, 36, 9, 3)):
+        with lap(gpu_pkg, n, 0) as s:
+            pl = s.gemv_plan()
+            assert (pl["R"], pl["U"], pl["split"], pl["light"], pl["grid"]) == (rows, steps, chip, 1, 256), pl
     monkeypatch.setenv("CGX_STREAM_MAX", "12288")
     with lap(gpu_pkg, 12000, 0) as s:
-        assert s.gemv_plan()["variant"] == 5
+        assert s.gemv_plan()["variant"] == 5 and s.gemv_plan()["split"] == 0
     monkeypatch.setenv("CGX_STREAM_MAX", "4096")
     with lap(gpu_pkg, 6000, 0) as s:
         assert s.gemv_plan()["variant"] == 1
