@@ -29,7 +29,7 @@ EXPORTS = [
     "cgx_solve", "cgx_solve_begin", "cgx_solve_steps", "cgx_solve_end", "cgx_get_gemv_samples",
     "cgx_get_update_samples",
     "cgx_probe_gemv", "cgx_probe_time_gemv", "cgx_probe_vector_ops", "cgx_probe_get_matrix_rows",
-    "cgx_probe_get_source_term", "cgx_probe_set_fault_after", "cgx_probe_set_resident_limit",
+    "cgx_probe_get_source_term", "cgx_probe_set_fault_after", "cgx_probe_set_resident_limit", "cgx_probe_persistent_plan",
     "cgx_probe_parse_matrix_market", "cgx_probe_p2p_mailbox_to_host", "cgx_probe_fill_matrix_hash",
     "cgx_probe_set_p2p_epoch", "cgx_probe_get_p2p_epoch", "cgx_probe_p2p_host_mailboxes", "cgx_probe_resident_test",
 ]
@@ -133,6 +133,7 @@ def lib():
         L.cgx_probe_get_source_term.argtypes = [vp, C.c_int, dp]
         L.cgx_probe_set_fault_after.argtypes = [vp, C.c_int]
         L.cgx_probe_set_resident_limit.argtypes = [vp, C.c_int]
+        L.cgx_probe_persistent_plan.argtypes = [C.c_int, C.c_int, C.c_long, C.c_int, C.POINTER(C.c_long)]
         L.cgx_probe_p2p_mailbox_to_host.argtypes = [vp]
         L.cgx_probe_fill_matrix_hash.argtypes = [vp, C.c_ulonglong, C.c_int, C.c_double]
         L.cgx_probe_p2p_host_mailboxes.argtypes = [vp, C.c_char_p, C.c_int]

@@ -290,6 +290,17 @@ cgx_status cgx_probe_p2p_host_mailboxes(cgx_ctx *ctx, const char *prefix, int st
     return CGX_OK;
 }
 
+cgx_status cgx_probe_persistent_plan(int n, int cus, long lds_per_cu, int streaming, long out[CGX_PERSISTENT_PLAN_INTS])
+{
+    if (!out || n < 1 || cus < 1 || lds_per_cu < 0) return CGX_ERR_BAD_ARG;
+    cgx::ResidentPlan pl{};
+    const bool fits = streaming ? cgx::plan_stream(n, cus, (size_t)lds_per_cu, &pl) : cgx::plan_resident(n, cus, (size_t)lds_per_cu, &pl);
+    const long r[CGX_PERSISTENT_PLAN_INTS] = {fits ? 1 : 0, pl.R, pl.S, pl.grid, pl.xslots, (long)pl.lds_bytes, pl.RL, pl.RG, pl.RB, pl.l2_rows,
+                                              pl.hybrid, pl.stream ? 512 : 256};
+    for (int i = 0; i < CGX_PERSISTENT_PLAN_INTS; ++i) out[i] = fits || i == 0 ? r[i] : 0;
+    return CGX_OK;
+}
+
 cgx_status cgx_probe_set_resident_limit(cgx_ctx *ctx, int workgroups)
 {
     if (!ctx) return CGX_ERR_BAD_ARG;

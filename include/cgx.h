@@ -285,6 +285,14 @@ cgx_status  cgx_probe_p2p_host_mailboxes(cgx_ctx *ctx, const char *prefix, int s
  * guards the LDS-resident solver (its workgroups wait for each other as well): with a bound below its grid the default falls
  * back to the per-launch path and gemv_variant 40000 is refused. */
 cgx_status  cgx_probe_set_resident_limit(cgx_ctx *ctx, int workgroups);
+/* TEST ONLY, host arithmetic (no device, no context): the shape the library would give a persistent kernel for a dense n x n
+ * problem on a GPU of `cus` compute units with `lds_per_cu` bytes of LDS a workgroup may use -- streaming = 0: the resident
+ * kernel (n <= 4096), 1: the streaming kernel (1024 <= n <= 16384).  out = {fits (0 / 1), R rows per workgroup, S column steps,
+ * grid, exchange slots per parity, LDS bytes per workgroup, rows in LDS, rows in registers, rows per batch of the ring
+ * (streaming), streamed rows read with the default cache policy (streaming), hybrid (resident: 1 = rows in LDS + registers + a
+ * streamed rest), threads per workgroup}.  tests/test_persistent_plans.py holds the invariants for every n. */
+#define CGX_PERSISTENT_PLAN_INTS 12
+cgx_status  cgx_probe_persistent_plan(int n, int cus, long lds_per_cu, int streaming, long out[CGX_PERSISTENT_PLAN_INTS]);
 /* TEST ONLY: the epoch counter of mailbox channel `chan` (0 = plain segment all-gathers of a tagged-word context, 1 = the
  * iteration's exchange, 2 = DEBUG scalars).  set: move it FORWARD to `value` (the next exchange is value + 1) so that tests
  * reach the wrap of the tagged form's 32-bit tag and of the epoch's low 32 bits without 4e9 exchanges; every rank makes the
