@@ -63,6 +63,10 @@ constexpr int kResThreads = 256;
 // S = 5: 7 + 9 + 0 (all resident, n <= 2560); S = 6: 6 + 10 + 0 (all resident, n <= 3072); S = 7: 5 + 10 + 1;
 // S = 8: 4 + 8 + 4 (n = 4096: 32 of 128 MiB re-read per iteration).
 // ------------------------------------------------------------------------------------------------------------------------
+// the pause between a workgroup's publish and its first look at the others' words (units of 64 clocks), and whether that first look is
+// at ONE watched word or at all of them (the table at the gather)
+constexpr int res_pause(int S) { return S <= 2 ? 16 : S == 3 ? 20 : S == 4 ? 24 : 16; }
+constexpr bool res_watch(int S) { return S >= 5; }
 constexpr int kHybR = 16;
 constexpr int hyb_rl(int S) { return (150 * 1024) / (S * 512 * 8) < kHybR ? (150 * 1024) / (S * 512 * 8) : kHybR; }
 // rows in registers: what the 512 registers of a thread hold beside r, p, the row sums, a batch of streamed rows and the
@@ -296,8 +300,16 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
             // units of s_sleep 1 (64 clocks): n = 512 / 1024 / 2048 / 4096: no delay 509 / 685 / 992 / 3134, 8: 382 / 530 / 926 / 3085,
             // 14: 333 / 497 / 923 / 3068, 16: 330 / 500 / 898 / 3063, 20: 353 / 522 / 910 / 3041, 28: 373 / 557 / 966 / 3070
             // (profiles/r05_window/poll_delay.txt): 2.8 us per iteration at n = 1024 instead of 3.3-3.9.
-            __builtin_amdgcn_s_sleep(16);
-            if (any) {
+            // Up to n = 2048 there is no watched word either: behind a pause of the right length the gather's first round finds all
+            // words there, and a poll in front of it is a round trip for nothing (what has not arrived is asked for again, as ever).
+            // Measured, us per iteration at n = 256 / 512 / 1024 / 1448 / 2048 / 2896 / 4096 (profiles/r05_nowatch/):
+            //   watched word, pause 16 (round 5 so far)   2.28 / 2.40 / 2.59 / 3.04 / 3.33 / 4.43 / 6.04
+            //   no watched word, pause 16                 1.94 / 2.05 / 2.26 / 2.98 / 3.46 / 4.65 / 6.43
+            //   no watched word, pause 20                 2.05 / 2.16 / 2.37 / 2.80 / 3.31 / 4.59 / 6.38
+            //   no watched word, pause 24                 2.15 / 2.26 / 2.47 / 2.90 / 3.12 / 4.37 / 6.42
+            // (above n = 2048 the workgroups' publishes lie further apart and the first round comes too early more often)
+            __builtin_amdgcn_s_sleep(res_pause(S));
+            if (any && res_watch(S)) {
                 const unsigned long long *watch = slot + 2 * (size_t)xpos(2 * tid);   // column 2 tid: valid whenever `any`
                 for (;;) {
                     u4 w = tagged_issue(watch);
