@@ -65,7 +65,10 @@ constexpr int kResThreads = 256;
 // ------------------------------------------------------------------------------------------------------------------------
 // the pause between a workgroup's publish and its first look at the others' words (units of 64 clocks), and whether that first look is
 // at ONE watched word or at all of them (the table at the gather)
-constexpr int res_pause(int S) { return S <= 2 ? 16 : S == 3 ? 20 : S == 4 ? 24 : 16; }
+// (a pause that is too short costs a second round of the gather, 0.25-0.35 us; one that is too long only its own length: the
+// values sit one step of 2 behind the edge measured in profiles/r05_nowatch/pause_scan.txt -- 14 | 16 at n <= 1024, 18 | 20 up to
+// 1536, 22 | 24 up to 2048)
+constexpr int res_pause(int S) { return S <= 2 ? 18 : S == 3 ? 22 : S == 4 ? 26 : 16; }
 constexpr bool res_watch(int S) { return S >= 5; }
 constexpr int kHybR = 16;
 constexpr int hyb_rl(int S) { return (150 * 1024) / (S * 512 * 8) < kHybR ? (150 * 1024) / (S * 512 * 8) : kHybR; }
@@ -307,6 +310,7 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
             //   no watched word, pause 16                 1.94 / 2.05 / 2.26 / 2.98 / 3.46 / 4.65 / 6.43
             //   no watched word, pause 20                 2.05 / 2.16 / 2.37 / 2.80 / 3.31 / 4.59 / 6.38
             //   no watched word, pause 24                 2.15 / 2.26 / 2.47 / 2.90 / 3.12 / 4.37 / 6.42
+            //   built: pause 18 / 22 / 26 (res_pause)     2.00 / 2.07 / 2.26 / 2.81 / 3.11
             // (above n = 2048 the workgroups' publishes lie further apart and the first round comes too early more often)
             __builtin_amdgcn_s_sleep(res_pause(S));
             if (any && res_watch(S)) {

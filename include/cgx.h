@@ -78,7 +78,7 @@ typedef struct cgx_config {
                                  block size -- or, for a dense matrix of n <= 16384 on one GPU (CGX_COMM_SELF), a PERSISTENT kernel:
                                  the whole loop cg.cc:95-137 as ONE launch whose workgroups exchange Ap among themselves.
                                  n <= 4096: every row group of A stays on the chip, in a CU's LDS (n <= 2048) or in its LDS and
-                                 registers with a streamed rest (csrc/cgx_resident.hip; 1.9-6 us per iteration instead of 7-26);
+                                 registers with a streamed rest (csrc/cgx_resident.hip; 2-6 us per iteration instead of 7-26);
                                  4096 < n <= 16384: the rows are streamed (all but the few that fit beside them), the vectors
                                  stay in registers (csrc/cgx_stream.hip; the default up to n = 9216, where it measures faster:
                                  18 / 71 / 92-95 us per iteration at n = 5120 / 8192 / 9216 instead of 36 / 80 / 104; CGX_STREAM_MAX
