@@ -109,6 +109,8 @@ struct cgx_ctx {
     unsigned res_stamp = 0;                  // the number of the most recent persistent launch (never 0 once one has run)
     long long res_rec[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the waits of the current solve's launches, summed up (cgx_get_resident_record)
     bool lean = false;                       // the solve under way began with the one-kernel set-up (zero initial guess, persistent kernel)
+    bool oneshot = false;                    // cgx_solve is running begin / steps / end in one go: the end may be enqueued behind the loop
+    bool end_enqueued = false;               // ... and has been (verification GEMV + end kernel are behind the persistent launch, h_stage is filled)
     long long res_fallbacks = 0;             // persistent launches of this context whose waits expired and that were redone on the per-launch path
 
     // loopback pointer tables (device)

@@ -376,11 +376,37 @@ cgx_status resident_steps(cgx_ctx *ctx, int nsteps, int *redo)
         a.mute_wg = ctx->res_mute_wg;
         ctx->res_mute_wg = -1;
         const cgx::ResidentTail *tail = ctx->h_res_tail;
-        {
+        // cgx_solve (begin, all of the loop, end in one call) from a zero initial guess: this launch ends the loop whatever happens in it,
+        // so what cgx_solve_end would enqueue -- the verification GEMV (cg.cc:146-147) and the end kernel -- goes behind it at once,
+        // on the block the launch writes, and ONE host synchronisation serves both (a second one and the idle gap in front of it
+        // were 20 us of the reference's window, 4 % of it at n = 1024).  A launch whose waits expired leaves garbage for those
+        // two kernels to chew on: nothing of it is used, the swap is undone, the solve goes on as below.
+        const bool spec = ctx->oneshot && ctx->lean && left <= kResidentBatch && !d_prof;
+        auto undo_spec = [&]() {
+            if (spec && ctx->end_enqueued) {
+                s.cur ^= 1;
+                bind_state(s, ctx->lda);
+                ctx->end_enqueued = false;
+            }
+        };
+        auto launch_and_wait = [&]() -> cgx_status {
             DeviceLock lock(ctx);
             HIP_TRY(ctx, cgx::launch_cg_resident(ctx->rplan, a, ctx->stream));
+            if (spec) {
+                s.cur ^= 1;                 // (speculatively: the block the launch writes)
+                bind_state(s, ctx->lda);
+                ctx->end_enqueued = true;
+                CGX_TRY(run_gemv_plain(ctx, s, s.x));
+                HIP_TRY(ctx, cgx::launch_solve_end(ctx->n, s.Ap(), s.b_full, s.x, s.sc, ctx->h_stage, ctx->stream));
+            }
             // no copy command: the kernel has written its report into pinned memory itself, the launch's stamp last
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            return CGX_OK;
+        };
+        const cgx_status launched = launch_and_wait();
+        if (launched != CGX_OK) {
+            undo_spec();
+            return launched;
         }
         const bool reported = tail->stamp == a.stamp;   // (always, once the kernel has ended; anything else is treated as a failed launch)
         if (reported) {
@@ -397,6 +423,7 @@ cgx_status resident_steps(cgx_ctx *ctx, int nsteps, int *redo)
         }
         int flags[3] = {reported ? tail->done : 0, reported ? tail->k_final : 0, reported ? tail->err : 1};
         if (flags[2]) {
+            undo_spec();
             // A wait for another workgroup's Ap expired: the grid was not resident at once.  Epochs that may have been used:
             ctx->res_epoch += (unsigned long long)batch;
             if (ctx->res_forced)
@@ -432,8 +459,10 @@ cgx_status resident_steps(cgx_ctx *ctx, int nsteps, int *redo)
         ctx->res_epoch += (unsigned long long)(ctx->done ? ctx->k_final - k0 + 1 : batch);
         ctx->k += batch;
         left -= batch;
-        s.cur ^= 1;                 // the block the launch wrote is the state now
-        bind_state(s, ctx->lda);
+        if (!spec) {
+            s.cur ^= 1;             // the block the launch wrote is the state now
+            bind_state(s, ctx->lda);
+        }
     }
     if (d_prof && ctx->rplan.stream) {
         // one line per workgroup for the stamped iteration: xcd, begin of its sweep, row sums done, Ap gathered (us after the earliest begin)
@@ -483,6 +512,7 @@ cgx_status cgx_solve_begin(cgx_ctx *ctx, const double *x0)
     // ONE kernel -- r = b - A 0 = b needs no GEMV.  With the persistent launch, the verification GEMV and the one-kernel
     // end (cgx_solve_end) the whole solve() is four launches and no copy command.
     ctx->lean = false;
+    ctx->end_enqueued = false;
     if (ctx->resident && ctx->h_stage && ctx->shards.size() == 1 && ctx->shards[0].state[0]) {
         bool zero = true;
         for (int i = 0; i < n && zero; ++i) zero = x0[i] == 0.0 && !std::signbit(x0[i]);
@@ -601,9 +631,12 @@ cgx_status cgx_solve_end(cgx_ctx *ctx, double *x, cgx_result *res)
         // the pad columns are zero), so the verification GEMV (cg.cc:146-147) takes it as it is, and ONE kernel does the DEBUG
         // norms (cg.cc:148-151) and puts x, the three sums and rs[] into the pinned buffer.
         Shard &s = ctx->shards[0];
-        CGX_TRY(run_gemv_plain(ctx, s, s.x));
-        HIP_TRY(ctx, cgx::launch_solve_end(ctx->n, s.Ap(), s.b_full, s.x, s.sc, ctx->h_stage, st));
-        HIP_TRY(ctx, hipStreamSynchronize(st));
+        if (!ctx->end_enqueued) {   // (cgx_solve has put both behind the persistent launch already: resident_steps)
+            CGX_TRY(run_gemv_plain(ctx, s, s.x));
+            HIP_TRY(ctx, cgx::launch_solve_end(ctx->n, s.Ap(), s.b_full, s.x, s.sc, ctx->h_stage, st));
+            HIP_TRY(ctx, hipStreamSynchronize(st));
+        }
+        ctx->end_enqueued = false;
         const double *o = ctx->h_stage + ctx->n;
         if (x) memcpy(x, ctx->h_stage, (size_t)ctx->n * sizeof(double));
         ctx->in_solve = false;
@@ -718,7 +751,13 @@ cgx_status cgx_solve(cgx_ctx *ctx, double *x, cgx_result *res)
     if (!ctx || !x) return fail(ctx, CGX_ERR_BAD_ARG, "cgx_solve: bad argument");
     CGX_TRY(cgx_solve_begin(ctx, x));
     int done = 0;
-    CGX_TRY(cgx_solve_steps(ctx, ctx->max_iter, &done));
+    ctx->oneshot = true;
+    const cgx_status st = cgx_solve_steps(ctx, ctx->max_iter, &done);
+    ctx->oneshot = false;
+    if (st != CGX_OK) {
+        ctx->end_enqueued = false;
+        return st;
+    }
     return cgx_solve_end(ctx, x, res);
 }
 
