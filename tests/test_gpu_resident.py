@@ -670,3 +670,27 @@ def test_context_life_cycles_leak_nothing(gpu_pkg):
             s.solve(np.zeros(n))
     mb1, fd1 = state()
     assert abs(mb1 - mb0) < 8 and fd1 == fd0, (mb0, mb1, fd0, fd1)
+
+
+def test_one_call_and_three_calls_give_the_same(gpu_pkg, monkeypatch):
+    """cgx_solve from a zero initial guess enqueues the verification GEMV and the end kernel behind the persistent launch and
+    synchronises once; begin / steps / end does it in three steps with a synchronisation each: the same bits in x and in every
+    field of the result, for the resident and the streaming kernel, converged and cut off, and with a non-zero initial guess (where
+    neither path is the lean one)."""
+    monkeypatch.delenv("CGX_RESIDENT", raising=False)
+    for n, iters, tol in ((1024, 400, 1e-10), (1024, 60, 0.0), (3000, 80, 0.0), (5000, 50, 0.0), (5000, 600, 1e-10)):
+        for x0 in (np.zeros(n), np.linspace(-1.0, 1.0, n)):
+            with lap(gpu_pkg, n, 0, iters, tol) as s:
+                assert s.gemv_plan()["variant"] in (4, 5)
+                xa = x0.copy()
+                ra = s.solve(xa)
+                s.solve_begin(x0)
+                s.solve_steps(iters)
+                xb = np.zeros(n)
+                rb = s.solve_end(xb)
+                xc = x0.copy()
+                rc = s.solve(xc)                         # and once more in one call, on the same context
+                assert s.resident_record()["fallbacks"] == 0
+            assert np.array_equal(xa, xb) and np.array_equal(xa, xc), (n, iters, tol)
+            for key in ("iterations", "converged", "residual_prev", "residual_last", "x_norm", "rel_residual"):
+                assert ra[key] == rb[key] == rc[key], (n, iters, tol, key)
