@@ -46,6 +46,8 @@ while time.time() - t0 < budget:
     k_ok = r1["iterations"] == ro["iterations"] and r1["converged"] == ro["converged"]
     worst = max(worst, err if k_ok else 0.0)
     cases += 1
+    if cases % 500 == 0:
+        print("... %d cases, %.0f s, worst %.3e" % (cases, time.time() - t0, worst), flush=True)
     if not same or (k_ok and not err <= 1e-11) or (not k_ok and tol == 0.0):
         bad += 1
         print("MISMATCH n=%d iters=%d hashed=%s tol=%g: err %.3e same=%s k %d/%d conv %d/%d" % (
