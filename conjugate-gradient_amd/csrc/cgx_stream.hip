@@ -89,7 +89,7 @@ __device__ __forceinline__ int batch_sum(double (&v)[RB], int lane)
 
 // S = column steps of 1024 (n <= 1024 S); RB = rows per batch = depth of the ring in rows (a power of two: the batch's row
 // sums are reduced together); CH = column steps per gather chunk (2 CH tagged words in flight per thread).
-// Registers (hipcc 7.2, tools/kernel_resources.py): p and r 8 S, the ring 4 RB S, a gather chunk 8 CH; the gathered Ap is
+// Registers (hipcc 7.2, tools/kernel_resources.py): p and r 8 S, the ring 4 RB S, a register row 4 S, a gather chunk 8 CH; the gathered Ap is
 // parked in LDS between p.Ap and the update of r (8 KB per column step), so it costs none.
 // RL + RG of a workgroup's rows (its first ones) do not stream: RL are copied into the LDS and RG into registers once per launch
 // (what the LDS holds beside the parked Ap, what the 256 registers of a thread hold beside r, p and the ring: stream_rl / stream_rg).
