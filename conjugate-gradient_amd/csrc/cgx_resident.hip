@@ -67,9 +67,10 @@ constexpr int kResThreads = 256;
 // at ONE watched word or at all of them (the table at the gather)
 // (a pause that is too short costs a second round of the gather, 0.25-0.35 us; one that is too long only its own length: the
 // values sit one step of 2 behind the edge measured in profiles/r05_nowatch/pause_scan.txt -- 14 | 16 at n <= 1024, 18 | 20 up to
-// 1536, 22 | 24 up to 2048)
-constexpr int res_pause(int S) { return S <= 2 ? 18 : S == 3 ? 22 : S == 4 ? 26 : 16; }
-constexpr bool res_watch(int S) { return S >= 5; }
+// 1536, 22 | 24 up to 2048; above, the optimum is flat: 26 up to n = 2560 (3.88-3.91 us at 24-26 against 4.03 with the watched word), 28 up to
+// 3072 (4.29-4.32 at 26-28 against 4.40); from n = 3073 the watched word with a pause of 16 is what measures best: pause_scan2.txt)
+constexpr int res_pause(int S) { return S <= 2 ? 18 : S == 3 ? 22 : S <= 5 ? 26 : S == 6 ? 28 : 16; }
+constexpr bool res_watch(int S) { return S >= 7; }
 constexpr int kHybR = 16;
 constexpr int hyb_rl(int S) { return (150 * 1024) / (S * 512 * 8) < kHybR ? (150 * 1024) / (S * 512 * 8) : kHybR; }
 // rows in registers: what the 512 registers of a thread hold beside r, p, the row sums, a batch of streamed rows and the
@@ -303,7 +304,7 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
             // units of s_sleep 1 (64 clocks): n = 512 / 1024 / 2048 / 4096: no delay 509 / 685 / 992 / 3134, 8: 382 / 530 / 926 / 3085,
             // 14: 333 / 497 / 923 / 3068, 16: 330 / 500 / 898 / 3063, 20: 353 / 522 / 910 / 3041, 28: 373 / 557 / 966 / 3070
             // (profiles/r05_window/poll_delay.txt): 2.8 us per iteration at n = 1024 instead of 3.3-3.9.
-            // Up to n = 2048 there is no watched word either: behind a pause of the right length the gather's first round finds all
+            // Up to n = 3072 there is no watched word either: behind a pause of the right length the gather's first round finds all
             // words there, and a poll in front of it is a round trip for nothing (what has not arrived is asked for again, as ever).
             // Measured, us per iteration at n = 256 / 512 / 1024 / 1448 / 2048 / 2896 / 4096 (profiles/r05_nowatch/):
             //   watched word, pause 16 (round 5 so far)   2.28 / 2.40 / 2.59 / 3.04 / 3.33 / 4.43 / 6.04
@@ -311,7 +312,8 @@ __global__ __launch_bounds__(kResThreads, 1) void k_cg_resident(ResidentArgs a)
             //   no watched word, pause 20                 2.05 / 2.16 / 2.37 / 2.80 / 3.31 / 4.59 / 6.38
             //   no watched word, pause 24                 2.15 / 2.26 / 2.47 / 2.90 / 3.12 / 4.37 / 6.42
             //   built: pause 18 / 22 / 26 (res_pause)     2.00 / 2.07 / 2.26 / 2.81 / 3.11
-            // (above n = 2048 the workgroups' publishes lie further apart and the first round comes too early more often)
+            // (above n = 3072 -- rows streamed every iteration -- the workgroups' publishes lie further apart and the first round comes too
+            // early more often)
             __builtin_amdgcn_s_sleep(res_pause(S));
             if (any && res_watch(S)) {
                 const unsigned long long *watch = slot + 2 * (size_t)xpos(2 * tid);   // column 2 tid: valid whenever `any`
