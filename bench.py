@@ -266,7 +266,7 @@ def cpu_baseline(n, iters):
 def reference_sizes(pkg, torch):
     """The reference's own experiment sizes (code/MPI/cg.run:15-44: N = 1024, 2048, 4096, 8192 ... to convergence or 200 iterations)
     and BASELINE.json configs[1]'s N = 10000 on this GPU: iterations/s of the loop with the library's default (n <= 4096: the resident
-    persistent kernel; n <= 9216: the streaming persistent kernel, section 4c; above: K1 + K3) and with the
+    persistent kernel; n <= 10000: the streaming persistent kernel, section 4c; above: K1 + K3) and with the
     per-launch path (K1 + K3 per iteration), tol = 0, timed iterations after 200, best of 3; `hbm_roofline_frac` = the whole
     iteration against the GEMV's algorithmic bytes 8 (n^2 + 2 n) at 8 TB/s.  Not the headline metric."""
     import numpy as np

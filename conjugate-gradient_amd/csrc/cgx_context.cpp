@@ -25,8 +25,12 @@ namespace cgxi {
 // N = 9216 by 8 % and more (17.9 / 31.8 / 50.6 / 70.5 / 95.3 us per iteration at N = 5120 / 6144 / 7168 / 8192 / 9216 against 36.1 / 47.7 /
 // 65.2 / 79.7 / 103.9, the slower of two boxes).  From N = 9500 to 11264 the two are within 3 % of each other, and which one is ahead
 // changes from box to box (N = 10000: 116.7 against 118.9 on one, 120.5 against 118.8 on the other -- the per-launch figure is the
-// stable one: a persistent kernel ends with its slowest workgroup); above, the streaming kernel loses
-constexpr int kStreamDefaultMax = 9216;
+// stable one: a persistent kernel ends with its slowest workgroup).  What decides up to N = 10000 (BASELINE config 2: N = 10000 run to
+// convergence, timed as the reference times it: all of solve() in a fresh process) is that window: `cgsolver 10000 out` 71.1-74.4 ms
+// through the streaming kernel, whose solve is four launches, against 77.5-78.6 through K1 + K3, on three boxes; 9500: 65.9 against
+// 66.5; 10240: 78.6 against 77.0 -- so the end is 10000.  Above S = 11 the streaming kernel has no row of A on the chip and loses
+// 
+constexpr int kStreamDefaultMax = 10000;
 
 thread_local std::string g_create_error;
 

@@ -80,8 +80,9 @@ typedef struct cgx_config {
                                  n <= 4096: every row group of A stays on the chip, in a CU's LDS (n <= 2048) or in its LDS and
                                  registers with a streamed rest (csrc/cgx_resident.hip; 2-6 us per iteration instead of 7-26);
                                  4096 < n <= 16384: the rows are streamed (all but the few that fit beside them), the vectors
-                                 stay in registers (csrc/cgx_stream.hip; the default up to n = 9216, where it measures faster:
-                                 18 / 71 / 92-95 us per iteration at n = 5120 / 8192 / 9216 instead of 36 / 80 / 104; CGX_STREAM_MAX
+                                 stay in registers (csrc/cgx_stream.hip; the default up to n = 10000, where it measures faster:
+                                 18 / 71 / 92-95 us per iteration at n = 5120 / 8192 / 9216 instead of 36 / 80 / 104, the solve
+                                 at n = 10000 in 71-74 ms instead of 78; CGX_STREAM_MAX
                                  moves that end).  What the default choice rests on, and what happens when it fails:
                                  all workgroups of such a kernel must be resident at once (checked against the runtime's
                                  occupancy when the problem is set; another tenant of the GPU can still break it), and the

@@ -215,8 +215,8 @@ def test_selection(gpu_pkg, monkeypatch):
     with lap(gpu_pkg, 4096, 0) as s:
         assert s.gemv_plan()["variant"] == 4
     with lap(gpu_pkg, 4097, 0) as s:               # above 4096 the matrix no longer fits the chip: the STREAMING persistent kernel
-        assert s.gemv_plan()["variant"] == 5       # (csrc/cgx_stream.hip, tests/test_gpu_stream.py), by default up to n = 9216
-    with lap(gpu_pkg, 9217, 0) as s:
+        assert s.gemv_plan()["variant"] == 5       # (csrc/cgx_stream.hip, tests/test_gpu_stream.py), by default up to n = 10000
+    with lap(gpu_pkg, 10001, 0) as s:
         assert s.gemv_plan()["variant"] == 1
     with lap(gpu_pkg, 1024, 10421) as s:
         assert s.gemv_plan()["variant"] == 1

@@ -7,7 +7,7 @@ that window would read a register whose load has not landed, and nothing validat
 487-511 of 512 registers, so a toolchain bump could introduce exactly that: this test fails the build if ANY instantiation of
 k_cg_resident spills a vector register or touches scratch.  csrc/cgx_stream.hip leaves every wait to the compiler (buffer-load
 builtins), so a spill there costs time, not correctness: the instantiations that hold rows of A on the chip (n <= 11264: S <= 11;
-the library's default uses them up to S = 9) must be spill-free -- they sit at 227-256 of 256 registers because every register that is free holds a piece
+the library's default uses them up to S = 10: n <= 10000) must be spill-free -- they sit at 227-256 of 256 registers because every register that is free holds a piece
 of a row of A; the others may spill outside the sweep (documented in DESIGN.md) but must still build."""
 import os
 import re
